@@ -1,0 +1,281 @@
+"""ctypes binding of the CPU oracle (oracle/orb_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liborb_oracle.so")
+
+
+class KeyPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float),
+                ("angle", C.c_float), ("response", C.c_float), ("octave", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"),
+                     ("response", "f4"), ("octave", "i4")])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    return C.CDLL(_SO)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+        L = _lib
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_get_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_extract.restype = C.c_int
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_get_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_get_blurred_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_get_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_get_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+# ---- primitives -------------------------------------------------------------
+def resize_linear(src, dw, dh):
+    src = _u8(src)
+    sh, sw = src.shape
+    dst = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_linear_8u(_p(src), sw, sh, sw, _p(dst), dw, dh, dw)
+    return dst
+
+
+def copy_make_border_101(src, pad):
+    src = _u8(src)
+    sh, sw = src.shape
+    dst = np.empty((sh + 2 * pad, sw + 2 * pad), np.uint8)
+    lib().orc_copy_make_border_101(_p(src), sw, sh, sw, _p(dst), sw + 2 * pad, pad)
+    return dst
+
+
+def fast9_16(img, threshold):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.empty((w * h, 3), np.int32)
+    n = lib().orc_fast9_16(_p(img), w, h, w, int(threshold), w * h, _p(out))
+    return out[:n].copy()
+
+
+def gaussian_taps():
+    t = np.zeros(7, np.int32)
+    lib().orc_gaussian_taps_7_s2(_p(t))
+    return t
+
+
+def gaussian_blur(img):
+    img = _u8(img)
+    h, w = img.shape
+    dst = np.empty((h, w), np.uint8)
+    lib().orc_gaussian_blur_7x7(_p(img), w, h, w, _p(dst), w)
+    return dst
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def distribute_octree(x, y, resp, min_x, max_x, min_y, max_y, n_target):
+    x, y, resp = _f32(x), _f32(y), _f32(resp)
+    out = np.empty(max(len(x), 1), np.int32)
+    n = lib().orc_distribute_octree(_p(x), _p(y), _p(resp), len(x), int(min_x), int(max_x),
+                                    int(min_y), int(max_y), int(n_target), _p(out))
+    if n < 0:
+        raise ValueError("reference behaviour undefined for this input (code %d)" % n)
+    return out[:n].copy()
+
+
+def descriptor_distance(a, b):
+    a, b = _u8(a), _u8(b)
+    return int(lib().orc_descriptor_distance(_p(a), _p(b)))
+
+
+def three_maxima(sizes):
+    sizes = _i32(sizes)
+    i1, i2, i3 = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
+
+
+# ---- extractor ----------------------------------------------------------------
+class Extractor:
+    """Mirror of ORBextractor (reference include/ORBextractor.h:95,113) on the CPU."""
+
+    def __init__(self, nfeatures, scale_factor, nlevels, ini_th, min_th):
+        self.h = lib().orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("bad extractor parameters")
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sf, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        quota = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        lib().orc_get_tables(self.h, _p(sf), _p(inv), _p(s2), _p(is2), _p(quota), _p(umax))
+        return dict(scale=sf, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+    def __call__(self, img, max_kp=None):
+        img = _u8(img)
+        rows, cols = img.shape
+        cap = max_kp if max_kp is not None else self.nfeatures * 2 + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = lib().orc_extract(self.h, _p(img), rows, cols, cols, cap, _p(kps), _p(desc))
+        if n < 0:
+            raise ValueError("reference behaviour undefined for this input (code %d)" % n)
+        assert n <= cap
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        if lib().orc_level_size(self.h, level, C.byref(w), C.byref(h)) != 0:
+            raise ValueError("no such level")
+        return w.value, h.value
+
+    def pyramid_level(self, level):
+        w, h = self.level_size(level)
+        out = np.empty((h + 38, w + 38), np.uint8)
+        lib().orc_get_pyramid_level(self.h, level, _p(out))
+        return out
+
+    def blurred_level(self, level):
+        w, h = self.level_size(level)
+        out = np.empty((h, w), np.uint8)
+        if lib().orc_get_blurred_level(self.h, level, _p(out)) != 0:
+            return None
+        return out
+
+    def candidates(self, level):
+        w, h = self.level_size(level)
+        out = np.empty((w * h // 4 + 16, 3), np.float32)
+        n = lib().orc_get_candidates(self.h, level, len(out), _p(out))
+        return out[:n].copy()
+
+    def level_keypoints(self, level):
+        out = np.zeros(self.nfeatures * 2 + 64, KP_DTYPE)
+        n = lib().orc_get_level_keypoints(self.h, level, len(out), _p(out))
+        return out[:n].copy()
+
+
+# ---- matchers -------------------------------------------------------------------
+def features_in_area(kx, ky, koct, bounds, x, y, r, min_level, max_level):
+    kx, ky, koct = _f32(kx), _f32(ky), _i32(koct)
+    out = np.empty(max(len(kx), 1), np.int32)
+    n = lib().orc_features_in_area(len(kx), _p(kx), _p(ky), _p(koct),
+                                   C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]),
+                                   C.c_float(x), C.c_float(y), C.c_float(r), int(min_level), int(max_level), _p(out))
+    return out[:n].copy()
+
+
+def search_by_projection_frames(Tcw, K, bounds, scale_factors, last, cur, th, check_ori=True):
+    """last: dict(mp_obs, xw, mp_desc, octave, angle); cur: dict(x, y, octave, angle, desc, obs).
+    Returns (nmatches, cur_match)."""
+    Tcw = _f32(Tcw).reshape(16)
+    sf = _f32(scale_factors)
+    l_obs, l_xw, l_desc = _i32(last["mp_obs"]), _f32(last["xw"]), _u8(last["mp_desc"])
+    l_oct, l_ang = _i32(last["octave"]), _f32(last["angle"])
+    c_x, c_y, c_oct, c_ang = _f32(cur["x"]), _f32(cur["y"]), _i32(cur["octave"]), _f32(cur["angle"])
+    c_desc, c_obs = _u8(cur["desc"]), _i32(cur["obs"])
+    match = np.empty(max(len(c_x), 1), np.int32)
+    f = C.c_float
+    n = lib().orc_search_by_projection_frames(
+        _p(Tcw), f(K[0]), f(K[1]), f(K[2]), f(K[3]), f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]), _p(sf),
+        len(l_obs), _p(l_obs), _p(l_xw), _p(l_desc), _p(l_oct), _p(l_ang),
+        len(c_x), _p(c_x), _p(c_y), _p(c_oct), _p(c_ang), _p(c_desc), _p(c_obs), f(th), int(check_ori), _p(match))
+    return n, match[:len(c_x)].copy()
+
+
+def search_by_projection_mappoints(bounds, scale_factors, frame, mps, th, nnratio):
+    """frame: dict(x, y, octave, desc, obs); mps: dict(track, level, viewcos, projx, projy, desc, obs)."""
+    sf = _f32(scale_factors)
+    f_x, f_y, f_oct, f_desc, f_obs = _f32(frame["x"]), _f32(frame["y"]), _i32(frame["octave"]), _u8(frame["desc"]), _i32(frame["obs"])
+    m_tr, m_lv, m_vc = _u8(mps["track"]), _i32(mps["level"]), _f32(mps["viewcos"])
+    m_px, m_py, m_desc, m_obs = _f32(mps["projx"]), _f32(mps["projy"]), _u8(mps["desc"]), _i32(mps["obs"])
+    match = np.empty(max(len(f_x), 1), np.int32)
+    f = C.c_float
+    n = lib().orc_search_by_projection_mappoints(
+        f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]), _p(sf),
+        len(f_x), _p(f_x), _p(f_y), _p(f_oct), _p(f_desc), _p(f_obs),
+        len(m_tr), _p(m_tr), _p(m_lv), _p(m_vc), _p(m_px), _p(m_py), _p(m_desc), _p(m_obs),
+        f(th), f(nnratio), _p(match))
+    return n, match[:len(f_x)].copy()
+
+
+def search_for_triangulation(kf1, kf2, fv1, fv2, F12, epipole, scale_factors2, level_sigma2_2, check_ori=False):
+    """kf: dict(x, y, octave, angle, desc, has_mp); fv: dict(node, start, items)."""
+    a = {}
+    for tag, kf in (("1", kf1), ("2", kf2)):
+        a["x" + tag], a["y" + tag] = _f32(kf["x"]), _f32(kf["y"])
+        a["o" + tag], a["a" + tag] = _i32(kf["octave"]), _f32(kf["angle"])
+        a["d" + tag], a["m" + tag] = _u8(kf["desc"]), _u8(kf["has_mp"])
+    n1, n2 = len(a["x1"]), len(a["x2"])
+    nd1, st1, it1 = _i32(fv1["node"]), _i32(fv1["start"]), _i32(fv1["items"])
+    nd2, st2, it2 = _i32(fv2["node"]), _i32(fv2["start"]), _i32(fv2["items"])
+    F12 = _f32(F12).reshape(9)
+    sf2, ls2 = _f32(scale_factors2), _f32(level_sigma2_2)
+    m12 = np.empty(max(n1, 1), np.int32)
+    f = C.c_float
+    n = lib().orc_search_for_triangulation(
+        n1, _p(a["x1"]), _p(a["y1"]), _p(a["o1"]), _p(a["a1"]), _p(a["d1"]), _p(a["m1"]),
+        n2, _p(a["x2"]), _p(a["y2"]), _p(a["o2"]), _p(a["a2"]), _p(a["d2"]), _p(a["m2"]),
+        len(nd1), _p(nd1), _p(st1), _p(it1), len(nd2), _p(nd2), _p(st2), _p(it2),
+        _p(F12), f(epipole[0]), f(epipole[1]), _p(sf2), _p(ls2), int(check_ori), _p(m12))
+    return n, m12[:n1].copy()
+
+
+def knn2_bruteforce(q, db, ratio):
+    q, db = _u8(q), _u8(db)
+    nq = len(q)
+    best, second, idx = (np.empty(max(nq, 1), np.int32) for _ in range(3))
+    acc = np.empty(max(nq, 1), np.uint8)
+    lib().orc_knn2_bruteforce(_p(q), nq, _p(db), len(db), C.c_float(ratio), _p(best), _p(second), _p(idx), _p(acc))
+    return best[:nq].copy(), second[:nq].copy(), idx[:nq].copy(), acc[:nq].copy()
