@@ -1,0 +1,214 @@
+/*
+ * orbhip.h -- C ABI of liborbhip.so: ORB extraction and Hamming matching on AMD
+ * MI355X (gfx950).  Plain C types, caller-owned buffers, int status codes, opaque
+ * handles; no exceptions cross this boundary.
+ *
+ * Each entry point names the ORB-SLAM2 interface it stands in for
+ * (zhangshaos/ORB_SLAM2, file:line).  Pointers marked "device" are HIP device
+ * pointers on the handle's GPU; everything else is host memory.
+ *
+ * Threading: an extractor handle serves one caller thread at a time (like an
+ * ORBextractor instance, which keeps its pyramid between calls); distinct handles
+ * are independent.  The matcher entry points keep no state and may be called
+ * concurrently.
+ */
+#ifndef ORBHIP_H_
+#define ORBHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define ORBHIP_OK 0
+#define ORBHIP_ERR_ARG (-1)        /* bad argument (null pointer, size out of range) */
+#define ORBHIP_ERR_UNSUPPORTED (-2) /* input for which the reference's behaviour is undefined,
+                                       or a size beyond this build's limits */
+#define ORBHIP_ERR_HIP (-3)        /* a HIP runtime call failed; see orb_last_error() */
+#define ORBHIP_ERR_CAPACITY (-4)   /* a caller-provided buffer was too small */
+
+/* Same fields as cv::KeyPoint as filled by ORBextractor::operator()
+ * (src/ORBextractor.cc:1164-1179,1323-1337): pt in level-0 pixels, size =
+ * int(31*scale[octave]), angle in degrees [0,360), response = FAST score. */
+typedef struct OrbKeyPoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+} OrbKeyPoint;
+
+typedef struct OrbExtractor OrbExtractor;
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* orb_last_error(void);
+
+/* Number of HIP devices visible, or a negative status. */
+int orb_device_count(void);
+
+/* ---- extractor ------------------------------------------------------------ */
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (include/ORBextractor.h:95, src/ORBextractor.cc:471-573) on GPU `device_id`. */
+int orb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                         int min_th_fast, int device_id, OrbExtractor** out);
+void orb_extractor_destroy(OrbExtractor* h);
+
+/* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:121-163).  Each array holds
+ * nlevels floats; null pointers are skipped.  Returns nlevels. */
+int orb_extractor_get_scale_tables(const OrbExtractor* h, float* scale, float* inv_scale,
+                                   float* sigma2, float* inv_sigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:511-528) and umax[0..15] (:544-572). */
+int orb_extractor_get_level_quotas(const OrbExtractor* h, int* quotas /* nlevels */, int* umax /* 16 */);
+/* Upper bound on keypoints per frame for the given image size (the quad-tree may
+ * return a few more than nfeatures, src/ORBextractor.cc:985).  <0 on error. */
+int orb_extractor_max_keypoints(OrbExtractor* h, int rows, int cols);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors)
+ * (src/ORBextractor.cc:1223-1339) for one host image (8-bit, one channel,
+ * `stride` bytes per row).  The mask is ignored by the reference and has no
+ * parameter here.  Writes at most max_kp keypoints and max_kp*32 descriptor bytes;
+ * *n_out receives the number found (ORBHIP_ERR_CAPACITY if it exceeds max_kp).
+ * An empty image (rows or cols == 0) returns ORBHIP_OK with *n_out = 0. */
+int orb_extract(OrbExtractor* h, const uint8_t* image, int rows, int cols, size_t stride,
+                int max_kp, OrbKeyPoint* keypoints, uint8_t* descriptors, int* n_out);
+
+/* The same for n_frames host images of one size; frame k starts at
+ * images + k*frame_stride.  keypoints/descriptors/n_out are [n_frames][max_kp],
+ * [n_frames][max_kp][32], [n_frames]. */
+int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int rows, int cols,
+                      size_t stride, size_t frame_stride, int max_kp, OrbKeyPoint* keypoints,
+                      uint8_t* descriptors, int* n_out);
+
+/* The same with every buffer resident on the handle's GPU.  The work is enqueued on
+ * `stream` (a hipStream_t; null = the handle's own stream) and not waited for; the
+ * call allocates only when the image size or n_frames grows beyond what the handle
+ * has already seen.  d_n_out[k] is the count found for frame k (may exceed max_kp,
+ * in which case only max_kp entries were written). */
+int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_images, int rows,
+                             int cols, size_t stride, size_t frame_stride, int max_kp,
+                             OrbKeyPoint* d_keypoints, uint8_t* d_descriptors, int* d_n_out,
+                             void* stream);
+/* Waits for everything enqueued on the handle's own stream. */
+int orb_extractor_sync(OrbExtractor* h);
+
+/* mvImagePyramid[level] of the last call (include/ORBextractor.h:166), frame `frame`
+ * of the batch.  padded != 0 returns the (h+38) x (w+38) image including the 19-px
+ * BORDER_REFLECT_101 frame (src/ORBextractor.cc:1385-1408), else the h x w level.
+ * dst may be null to query the size only. */
+int orb_get_pyramid_level(OrbExtractor* h, int frame, int level, int padded, uint8_t* dst,
+                          size_t dst_stride, int* width, int* height);
+/* The 7x7 sigma-2 blurred copy of a level that the descriptors were sampled from
+ * (src/ORBextractor.cc:1297-1305). */
+int orb_get_blurred_level(OrbExtractor* h, int frame, int level, uint8_t* dst, size_t dst_stride,
+                          int* width, int* height);
+/* vToDistributeKeys of a level (src/ORBextractor.cc:1061-1146): FAST corners after
+ * cell-local non-maximum suppression, as (x, y, response) with x, y relative to the
+ * (16,16) border origin, in the reference's cell-row-major / raster order.
+ * Returns the count (writes at most max_n triplets). */
+int orb_get_fast_candidates(OrbExtractor* h, int frame, int level, int max_n, float* xyr);
+/* Keypoints of one level after quad-tree distribution (src/ORBextractor.cc:1156-1179),
+ * level coordinates, in the reference's list order: (x, y, response) triplets. */
+int orb_get_level_keypoints(OrbExtractor* h, int frame, int level, int max_n, float* xyr);
+
+/* ---- matcher ---------------------------------------------------------------- */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1991-2011) for n pairs:
+ * out[i] = popcount(a[i] ^ b[i]) over 256 bits.  Host buffers; the pairs are
+ * evaluated on the GPU `device_id`. */
+int orb_hamming_distance_pairs(int device_id, const uint8_t* a, const uint8_t* b, int n, int* out);
+
+/* Window geometry shared by the projection matchers: Frame::mnMinX.. and the 64x48
+ * grid of Frame::AssignFeaturesToGrid / GetFeaturesInArea (src/Frame.cc:190-213,
+ * 371-449, 461-477). */
+typedef struct OrbFrameBounds {
+  float min_x, max_x, min_y, max_y;
+} OrbFrameBounds;
+
+/* ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono)
+ * (src/ORBmatcher.cc:1633-1788), for n_pairs independent (Last, Cur) frame pairs
+ * with the same intrinsics; pair p uses slices [p*max_last, ...) / [p*max_cur, ...)
+ * of the arrays.  Host buffers.
+ *   tcw        [n_pairs][16]  Cur.mTcw, row major
+ *   n_last     [n_pairs]      LastFrame.N
+ *   last_mp_obs[..max_last]   -1 where LastFrame.mvpMapPoints[i] is null, else its Observations()
+ *   last_xw    [..max_last][3] GetWorldPos()
+ *   last_mp_desc[..][32]      GetDescriptor()
+ *   last_octave, last_angle   LastFrame.mvKeys[i].octave, mvKeysUn[i].angle
+ *   n_cur, cur_x, cur_y, cur_octave, cur_angle, cur_desc   Cur.mvKeysUn / mDescriptors
+ *   cur_obs    [..max_cur]    -1 where Cur.mvpMapPoints[i2] is null, else its Observations()
+ *   scale_factors [nlevels]   Cur.mvScaleFactors
+ * Outputs:
+ *   cur_match  [..max_cur]    -1 untouched; i >= 0: Cur.mvpMapPoints[i2] = LastFrame.mvpMapPoints[i];
+ *                             -2: set and then nulled by the rotation-consistency check
+ *   n_matches  [n_pairs]      the function's return value
+ */
+int orb_search_by_projection_frames(
+    int device_id, int n_pairs, int max_last, int max_cur, const float* tcw, float fx, float fy,
+    float cx, float cy, OrbFrameBounds bounds, const float* scale_factors, int nlevels,
+    const int* n_last, const int* last_mp_obs, const float* last_xw, const uint8_t* last_mp_desc,
+    const int* last_octave, const float* last_angle, const int* n_cur, const float* cur_x,
+    const float* cur_y, const int* cur_octave, const float* cur_angle, const uint8_t* cur_desc,
+    const int* cur_obs, float th, int check_orientation, int* cur_match, int* n_matches);
+
+/* ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:64-158) for one frame.  Per map point: mp_track =
+ * mbNeedTrackInView && !isBad(), mnTrackedScaleLevel, mTrackedViewCosine,
+ * mTrackedProjX/Y, GetDescriptor(), Observations().  f_obs as cur_obs above.
+ * f_match[idx] = index of the map point stored in F.mvpMapPoints[idx], or -1. */
+int orb_search_by_projection_mappoints(
+    int device_id, OrbFrameBounds bounds, const float* scale_factors, int nlevels, int n_f,
+    const float* f_x, const float* f_y, const int* f_octave, const uint8_t* f_desc,
+    const int* f_obs, int n_mp, const uint8_t* mp_track, const int* mp_level,
+    const float* mp_viewcos, const float* mp_projx, const float* mp_projy, const uint8_t* mp_desc,
+    const int* mp_obs, float th, float nnratio, int* f_match, int* n_matches);
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)
+ * (src/ORBmatcher.cc:853-1048).  The two DBoW2::FeatureVector maps arrive as sorted
+ * node ids with CSR item lists; (ex, ey) is the epipole of KF1's centre in KF2
+ * (:862-871); has_mp = GetMapPoint(idx) != null.  matches12[idx1] = idx2 or -1. */
+int orb_search_for_triangulation(
+    int device_id, int n1, const float* x1, const float* y1, const int* octave1,
+    const float* angle1, const uint8_t* desc1, const uint8_t* has_mp1, int n2, const float* x2,
+    const float* y2, const int* octave2, const float* angle2, const uint8_t* desc2,
+    const uint8_t* has_mp2, int n_nodes1, const int* node1, const int* start1, const int* items1,
+    int n_nodes2, const int* node2, const int* start2, const int* items2, const float* f12,
+    float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int nlevels,
+    int check_orientation, int* matches12, int* n_matches);
+
+/* Brute-force Hamming 2-nearest-neighbour search with the ratio test of the
+ * reference's BoW / initialisation matchers ((float)best < ratio*(float)second,
+ * src/ORBmatcher.cc:312,616): for each of n_q query descriptors the smallest and
+ * second-smallest DescriptorDistance over n_db database rows (first minimum wins
+ * ties, as in the reference's sequential scans).  All pointers are DEVICE pointers;
+ * enqueued on `stream` and not waited for.
+ *   db_index_base  global index of d_db row 0 (database shards of a multi-GPU job)
+ *   d_best, d_second  [n_q] distances (256 = none);  d_idx [n_q] global row or -1
+ *   d_accept [n_q] ratio-test decision, may be null. */
+int orb_knn2_device(int device_id, const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db,
+                    int db_index_base, float ratio, int* d_best, int* d_second, int* d_idx,
+                    uint8_t* d_accept, void* stream);
+/* Merge of per-shard kNN-2 results (shards in ascending database order):
+ * in arrays are [n_shards][n_q]; the merged result equals a single scan of the
+ * concatenated database.  Device pointers. */
+int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_best,
+                          const int* d_second, const int* d_idx, float ratio, int* d_out_best,
+                          int* d_out_second, int* d_out_idx, uint8_t* d_out_accept, void* stream);
+/* Host-buffer convenience wrapper around orb_knn2_device on one GPU. */
+int orb_knn2_bruteforce(int device_id, const uint8_t* q, int n_q, const uint8_t* db, int n_db,
+                        float ratio, int* best, int* second, int* idx, uint8_t* accept);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBHIP_H_ */

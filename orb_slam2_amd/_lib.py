@@ -1,0 +1,88 @@
+"""ctypes loader for liborbhip.so (the HIP kernels + C ABI).  There is no fallback:
+if the library is missing or cannot be loaded, importing a compute entry point fails."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbhip.so")
+
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_CAPACITY = 0, -1, -2, -3, -4
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"),
+                     ("response", "f4"), ("octave", "i4")])
+
+
+class OrbHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class FrameBounds(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+_lib = None
+
+# every symbol include/orbhip.h declares
+EXPORTS = [
+    "orb_last_error", "orb_device_count", "orb_extractor_create", "orb_extractor_destroy",
+    "orb_extractor_get_scale_tables", "orb_extractor_get_level_quotas", "orb_extractor_max_keypoints",
+    "orb_extract", "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync",
+    "orb_get_pyramid_level", "orb_get_blurred_level", "orb_get_fast_candidates", "orb_get_level_keypoints",
+    "orb_hamming_distance_pairs", "orb_search_by_projection_frames", "orb_search_by_projection_mappoints",
+    "orb_search_for_triangulation", "orb_knn2_device", "orb_knn2_merge_device", "orb_knn2_bruteforce",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("liborbhip.so not built: run `make -C orb_slam2_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orb_last_error.restype = C.c_char_p
+    L.orb_extractor_create.argtypes = [i, f, i, i, i, i, C.POINTER(vp)]
+    L.orb_extractor_destroy.argtypes = [vp]
+    L.orb_extractor_destroy.restype = None
+    L.orb_extractor_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orb_extractor_get_level_quotas.argtypes = [vp, vp, vp]
+    L.orb_extractor_max_keypoints.argtypes = [vp, i, i]
+    L.orb_extract.argtypes = [vp, vp, i, i, sz, i, vp, vp, vp]
+    L.orb_extract_batch.argtypes = [vp, i, vp, i, i, sz, sz, i, vp, vp, vp]
+    L.orb_extract_batch_device.argtypes = [vp, i, vp, i, i, sz, sz, i, vp, vp, vp, vp]
+    L.orb_extractor_sync.argtypes = [vp]
+    L.orb_get_pyramid_level.argtypes = [vp, i, i, i, vp, sz, C.POINTER(i), C.POINTER(i)]
+    L.orb_get_blurred_level.argtypes = [vp, i, i, vp, sz, C.POINTER(i), C.POINTER(i)]
+    L.orb_get_fast_candidates.argtypes = [vp, i, i, i, vp]
+    L.orb_get_level_keypoints.argtypes = [vp, i, i, i, vp]
+    if not hasattr(L, "orb_knn2_bruteforce"):  # MATCHER-BIND (dev)
+        _lib = L
+        return L
+    L.orb_hamming_distance_pairs.argtypes = [i, vp, vp, i, vp]
+    L.orb_search_by_projection_frames.argtypes = (
+        [i, i, i, i, vp, f, f, f, f, FrameBounds, vp, i] + [vp] * 13 + [f, i, vp, vp])
+    L.orb_search_by_projection_mappoints.argtypes = (
+        [i, FrameBounds, vp, i, i] + [vp] * 5 + [i] + [vp] * 7 + [f, f, vp, vp])
+    L.orb_search_for_triangulation.argtypes = (
+        [i, i] + [vp] * 6 + [i] + [vp] * 6 + [i, vp, vp, vp, i, vp, vp, vp, vp, f, f, vp, vp, i, i, vp, vp])
+    L.orb_knn2_device.argtypes = [i, vp, i, vp, i, i, f, vp, vp, vp, vp, vp]
+    L.orb_knn2_merge_device.argtypes = [i, i, i, vp, vp, vp, f, vp, vp, vp, vp, vp]
+    L.orb_knn2_bruteforce.argtypes = [i, vp, i, vp, i, f, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise OrbHipError(rc, lib().orb_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,537 @@
+// Host side of the extractor: parameter tables, per-image-size plan, device buffers,
+// launch sequence and the extern "C" entry points declared in include/orbhip.h.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "orb_common.h"
+
+namespace orbhip {
+
+// launchers and limits defined next to the kernels
+void launch_pyr_level0(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, int, hipStream_t);
+void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
+void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, uint32_t*, int*, int, int, int, hipStream_t);
+void launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, hipStream_t);
+void launch_blur(const uint8_t*, uint8_t*, const Plan&, const BlurItem*, int, const int*, int, hipStream_t);
+void launch_orient_desc(const uint8_t*, const uint8_t*, const uint32_t*, const int*, const Plan&, OrbKeyPoint*,
+                        uint8_t*, int*, int, int, hipStream_t);
+int fast_use_width();
+int fast_max_cells();
+int fast_max_view_h();
+int octree_max_slots();
+int blur_tile_w();
+int blur_tile_h();
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return ORBHIP_ERR_HIP;
+}
+
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline int cv_round(double v) { return (int)lrint(v); }
+
+}  // namespace orbhip
+
+using namespace orbhip;
+
+struct OrbExtractor {
+  int nfeatures, nlevels, iniTh, minTh, device;
+  double scaleFactor;
+  float sf[kMaxLevels], inv_sf[kMaxLevels], sigma2[kMaxLevels], inv_sigma2[kMaxLevels];
+  int quota[kMaxLevels];
+  int umax[16];
+  int taps[4];
+  hipStream_t stream = nullptr;
+
+  // plan for the current image size
+  Plan plan{};
+  bool have_plan = false;
+  int cap_frames = 0;  // frames the buffers can hold
+  int last_frames = 0;
+  std::vector<FastItem> fast_items;
+  std::vector<BlurItem> blur_items;
+  // device buffers
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+  XTab* d_xtab = nullptr;
+  YTab* d_ytab = nullptr;
+  FastItem* d_fast_items = nullptr;
+  BlurItem* d_blur_items = nullptr;
+  uint32_t *d_cand = nullptr, *d_pnode = nullptr, *d_sel = nullptr;
+  int *d_cand_cnt = nullptr, *d_sel_cnt = nullptr;
+  // staging for the host-buffer entry points
+  uint8_t* d_img = nullptr;
+  size_t d_img_bytes = 0;
+  OrbKeyPoint* d_kps = nullptr;
+  uint8_t* d_desc = nullptr;
+  int* d_nout = nullptr;
+  size_t out_cap = 0;  // frames*max_kp the output staging holds
+  int out_frames = 0;
+};
+
+namespace {
+
+void free_plan_buffers(OrbExtractor* h) {
+  hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_xtab); hipFree(h->d_ytab);
+  hipFree(h->d_fast_items); hipFree(h->d_blur_items); hipFree(h->d_cand); hipFree(h->d_pnode);
+  hipFree(h->d_sel); hipFree(h->d_cand_cnt); hipFree(h->d_sel_cnt);
+  h->d_pyr = h->d_blur = nullptr; h->d_xtab = nullptr; h->d_ytab = nullptr;
+  h->d_fast_items = nullptr; h->d_blur_items = nullptr;
+  h->d_cand = h->d_pnode = h->d_sel = nullptr; h->d_cand_cnt = h->d_sel_cnt = nullptr;
+  h->have_plan = false; h->cap_frames = 0;
+}
+
+// cv::resize(INTER_LINEAR) coefficient tables for one axis: source index and the two
+// 11-bit fixed-point weights of every destination index.
+void resize_axis(int dn, int sn, std::vector<int>& ofs, std::vector<int16_t>& w0, std::vector<int16_t>& w1) {
+  const double scale = 1.0 / ((double)dn / sn);
+  ofs.resize(dn); w0.resize(dn); w1.resize(dn);
+  for (int d = 0; d < dn; d++) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(fx);
+    fx -= s;
+    ofs[d] = s;
+    auto sat = [](int v) { return (int16_t)std::min(std::max(v, -32768), 32767); };
+    // the caller decides how out-of-range indices are clamped (x and y differ in OpenCV)
+    w0[d] = sat(cv_round((1.f - fx) * 2048));
+    w1[d] = sat(cv_round(fx * 2048));
+  }
+}
+
+int build_plan(OrbExtractor* h, int rows, int cols, Plan& P, std::vector<XTab>& xtab, std::vector<YTab>& ytab,
+               std::vector<FastItem>& fitems, std::vector<BlurItem>& bitems) {
+  memset(&P, 0, sizeof(P));
+  P.nlevels = h->nlevels; P.rows = rows; P.cols = cols;
+  size_t off = 0;
+  int cand_off = 0, sel_off = 0;
+  xtab.clear(); ytab.clear(); fitems.clear(); bitems.clear();
+  for (int l = 0; l < h->nlevels; l++) {
+    LevelGeom& L = P.lv[l];
+    const float scale = h->inv_sf[l];
+    L.w = cv_round((float)cols * scale);
+    L.h = cv_round((float)rows * scale);
+    if (L.w - 2 * kBorder > kCoordMask || L.h - 2 * kBorder > kCoordMask || L.w > 65000 || L.h > 65000) {
+      set_error("image too large: level coordinates must fit 12 bits (at most 4127 px per side)");
+      return ORBHIP_ERR_UNSUPPORTED;
+    }
+    L.pitch = (L.w + kXOff + kEdge + 63) / 64 * 64;
+    L.off = (int)off;
+    off += (size_t)L.pitch * (L.h + 2 * kEdge);
+    off = (off + 255) / 256 * 256;
+    if (off > 0x7fffffffull) { set_error("frame slab exceeds 2 GiB"); return ORBHIP_ERR_UNSUPPORTED; }
+    L.maxBX = L.w - kBorder; L.maxBY = L.h - kBorder;
+    const float width = (float)(L.maxBX - kBorder), height = (float)(L.maxBY - kBorder);
+    L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
+    if (L.nCols < 1 || L.nRows < 1) {
+      set_error("pyramid level " + std::to_string(l) + " is smaller than 62 px: the reference divides by zero here");
+      return ORBHIP_ERR_UNSUPPORTED;
+    }
+    L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows);
+    if (L.hCell + 6 > fast_max_view_h() || L.wCell > fast_use_width()) {
+      set_error("cell size out of range"); return ORBHIP_ERR_UNSUPPORTED;
+    }
+    L.nValidCols = 0; L.nValidRows = 0;
+    for (int j = 0; j < L.nCols; j++) if (kBorder + j * L.wCell < L.maxBX - 6) L.nValidCols++;
+    for (int i = 0; i < L.nRows; i++) if (kBorder + i * L.hCell < L.maxBY - 3) L.nValidRows++;
+    L.quota = h->quota[l];
+    L.nIni = (int)roundf(width / (float)(L.maxBY - kBorder));
+    if (L.nIni < 1) {
+      set_error("level aspect ratio below 0.5: the reference's quad-tree has no root here");
+      return ORBHIP_ERR_UNSUPPORTED;
+    }
+    L.hX = width / L.nIni;
+    const int max_nodes = std::max(L.quota + 3, 4 * L.nIni);
+    if (max_nodes + L.nIni + 8 > octree_max_slots()) {
+      set_error("nfeatures too large for this build: a level needs " + std::to_string(max_nodes) +
+                " quad-tree nodes, limit " + std::to_string(octree_max_slots() - L.nIni - 8));
+      return ORBHIP_ERR_UNSUPPORTED;
+    }
+    L.cand_off = cand_off;
+    L.cand_cap = L.nValidCols * L.nValidRows * ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+    cand_off += (L.cand_cap + 63) / 64 * 64;
+    L.sel_off = sel_off;
+    L.sel_cap = max_nodes + 1;
+    sel_off += L.sel_cap;
+    L.scale = h->sf[l];
+    L.kp_size = (float)(int)(31 * h->sf[l]);
+    // resize tables (level l from level l-1)
+    L.xtab_off = (int)xtab.size(); L.ytab_off = (int)ytab.size();
+    if (l > 0) {
+      const LevelGeom& S = P.lv[l - 1];
+      std::vector<int> ofs; std::vector<int16_t> w0, w1;
+      resize_axis(L.w, S.w, ofs, w0, w1);
+      for (int d = 0; d < L.w; d++) {
+        XTab t{};
+        int s = ofs[d]; int16_t a0 = w0[d], a1 = w1[d];
+        if (s < 0) { s = 0; a0 = 2048; a1 = 0; }
+        if (s >= S.w - 1) { s = S.w - 1; a0 = 2048; a1 = 0; }
+        t.sx = (uint16_t)s; t.a0 = a0; t.a1 = a1;
+        xtab.push_back(t);
+      }
+      resize_axis(L.h, S.h, ofs, w0, w1);
+      for (int d = 0; d < L.h; d++) {
+        YTab t{};
+        auto clip = [&](int v) { return v < 0 ? 0 : (v < S.h ? v : S.h - 1); };
+        t.sy0 = (uint16_t)clip(ofs[d]); t.sy1 = (uint16_t)clip(ofs[d] + 1);
+        t.b0 = w0[d]; t.b1 = w1[d];
+        ytab.push_back(t);
+      }
+    }
+    // FAST work items: runs of cells per cell row
+    const int G = std::max(1, std::min(fast_max_cells(), fast_use_width() / L.wCell));
+    for (int i = 0; i < L.nValidRows; i++)
+      for (int j0 = 0; j0 < L.nValidCols; j0 += G) {
+        FastItem it; it.level = (int16_t)l; it.row = (int16_t)i; it.j0 = (int16_t)j0;
+        it.ncells = (int16_t)std::min(G, L.nValidCols - j0);
+        fitems.push_back(it);
+      }
+    for (int ty = 0; ty * blur_tile_h() < L.h; ty++)
+      for (int tx = 0; tx * blur_tile_w() < L.w; tx++) {
+        BlurItem it; it.level = (int16_t)l; it.tx = (int16_t)tx; it.ty = (int16_t)ty; it.pad = 0;
+        bitems.push_back(it);
+      }
+  }
+  P.slab = off;
+  P.cand_total = cand_off;
+  P.sel_total = sel_off;
+  return ORBHIP_OK;
+}
+
+int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
+  if (h->have_plan && h->plan.rows == rows && h->plan.cols == cols && nframes <= h->cap_frames) return ORBHIP_OK;
+  Plan P; std::vector<XTab> xtab; std::vector<YTab> ytab; std::vector<FastItem> fi; std::vector<BlurItem> bi;
+  int rc = build_plan(h, rows, cols, P, xtab, ytab, fi, bi);
+  if (rc != ORBHIP_OK) return rc;
+  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const int cap = std::max(nframes, (h->have_plan && h->plan.rows == rows && h->plan.cols == cols) ? h->cap_frames : 0);
+  free_plan_buffers(h);
+  ORB_HIP_CHECK(hipMalloc(&h->d_pyr, P.slab * cap));
+  ORB_HIP_CHECK(hipMalloc(&h->d_blur, P.slab * cap));
+  ORB_HIP_CHECK(hipMemsetAsync(h->d_pyr, 0, P.slab * cap, h->stream));
+  ORB_HIP_CHECK(hipMemsetAsync(h->d_blur, 0, P.slab * cap, h->stream));
+  ORB_HIP_CHECK(hipMalloc(&h->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1)));
+  ORB_HIP_CHECK(hipMalloc(&h->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1)));
+  ORB_HIP_CHECK(hipMalloc(&h->d_fast_items, sizeof(FastItem) * fi.size()));
+  ORB_HIP_CHECK(hipMalloc(&h->d_blur_items, sizeof(BlurItem) * bi.size()));
+  ORB_HIP_CHECK(hipMemcpyAsync(h->d_xtab, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice, h->stream));
+  ORB_HIP_CHECK(hipMemcpyAsync(h->d_ytab, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice, h->stream));
+  ORB_HIP_CHECK(hipMemcpyAsync(h->d_fast_items, fi.data(), sizeof(FastItem) * fi.size(), hipMemcpyHostToDevice, h->stream));
+  ORB_HIP_CHECK(hipMemcpyAsync(h->d_blur_items, bi.data(), sizeof(BlurItem) * bi.size(), hipMemcpyHostToDevice, h->stream));
+  ORB_HIP_CHECK(hipMalloc(&h->d_cand, sizeof(uint32_t) * (size_t)P.cand_total * cap));
+  ORB_HIP_CHECK(hipMalloc(&h->d_pnode, sizeof(uint32_t) * (size_t)P.cand_total * cap));
+  ORB_HIP_CHECK(hipMalloc(&h->d_sel, sizeof(uint32_t) * (size_t)P.sel_total * cap));
+  ORB_HIP_CHECK(hipMalloc(&h->d_cand_cnt, sizeof(int) * (size_t)P.nlevels * cap));
+  ORB_HIP_CHECK(hipMalloc(&h->d_sel_cnt, sizeof(int) * (size_t)P.nlevels * cap));
+  ORB_HIP_CHECK(hipMemsetAsync(h->d_sel_cnt, 0, sizeof(int) * (size_t)P.nlevels * cap, h->stream));
+  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
+  h->plan = P; h->fast_items = fi; h->blur_items = bi;
+  h->have_plan = true; h->cap_frames = cap; h->last_frames = 0;
+  return ORBHIP_OK;
+}
+
+int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride, size_t frame_stride, int max_kp,
+            OrbKeyPoint* d_kps, uint8_t* d_desc, int* d_nout, hipStream_t st) {
+  const Plan& P = h->plan;
+  ORB_HIP_CHECK(hipMemsetAsync(h->d_cand_cnt, 0, sizeof(int) * (size_t)P.nlevels * nframes, st));
+  launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, nframes, st);
+  for (int l = 1; l < P.nlevels; l++) launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
+  launch_fast(h->d_pyr, P, h->d_fast_items, (int)h->fast_items.size(), h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
+              nframes, st);
+  launch_octree(h->d_cand, h->d_cand_cnt, h->d_pnode, h->d_sel, h->d_sel_cnt, P, nframes, st);
+  launch_blur(h->d_pyr, h->d_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
+  launch_orient_desc(h->d_pyr, h->d_blur, h->d_sel, h->d_sel_cnt, P, d_kps, d_desc, d_nout, max_kp, nframes, st);
+  ORB_HIP_CHECK(hipGetLastError());
+  h->last_frames = nframes;
+  return ORBHIP_OK;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { hipGetDevice(&prev); if (prev != dev) hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* orb_last_error(void) { return g_err.c_str(); }
+
+int orb_device_count(void) {
+  int n = 0;
+  ORB_HIP_CHECK(hipGetDeviceCount(&n));
+  return n;
+}
+
+int orb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                         int device_id, OrbExtractor** out) {
+  if (!out) { set_error("out is null"); return ORBHIP_ERR_ARG; }
+  *out = nullptr;
+  if (nlevels < 1 || nlevels > kMaxLevels) { set_error("nlevels must be in 1.." + std::to_string(kMaxLevels)); return ORBHIP_ERR_ARG; }
+  if (nfeatures < 1 || !(scale_factor > 1.0f)) { set_error("nfeatures must be positive and scaleFactor > 1"); return ORBHIP_ERR_ARG; }
+  int ndev = 0;
+  ORB_HIP_CHECK(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) { set_error("no such device"); return ORBHIP_ERR_ARG; }
+  OrbExtractor* h = new OrbExtractor();
+  h->nfeatures = nfeatures; h->nlevels = nlevels; h->device = device_id;
+  h->iniTh = std::min(std::max(ini_th_fast, 0), 255);  // cv::FAST clamps its threshold
+  h->minTh = std::min(std::max(min_th_fast, 0), 255);
+  h->scaleFactor = scale_factor;
+  // scale tables and per-level quotas, reference src/ORBextractor.cc:480-528
+  h->sf[0] = 1.f; h->sigma2[0] = 1.f;
+  for (int i = 1; i < nlevels; i++) {
+    h->sf[i] = (float)(h->sf[i - 1] * h->scaleFactor);
+    h->sigma2[i] = h->sf[i] * h->sf[i];
+  }
+  for (int i = 0; i < nlevels; i++) { h->inv_sf[i] = 1.f / h->sf[i]; h->inv_sigma2[i] = 1.f / h->sigma2[i]; }
+  const float factor = (float)(1.0 / h->scaleFactor);
+  float want = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) { h->quota[l] = cv_round(want); sum += h->quota[l]; want *= factor; }
+  h->quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+  // row half-widths of the orientation disc, :544-572
+  {
+    const int R = 15;
+    const int vmax = (int)floor(R * sqrt(2.f) / 2 + 1), vmin = (int)ceil(R * sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) h->umax[v] = cv_round(sqrt((double)R * R - v * v));
+    for (int v = R, v0 = 0; v >= vmin; --v) {
+      while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+      h->umax[v] = v0; ++v0;
+    }
+    static const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    if (memcmp(expect, h->umax, sizeof(expect)) != 0) { delete h; set_error("umax table mismatch"); return ORBHIP_ERR_UNSUPPORTED; }
+  }
+  // 7-tap sigma-2 Gaussian in 8.8 fixed point, rounding error carried to the next tap,
+  // centre tap takes the remainder so that the taps sum to 256
+  {
+    double k[7], s = 0;
+    for (int i = 0; i < 7; i++) { const double x = i - 3.0; k[i] = exp(-0.125 * x * x); s += k[i]; }
+    s = 1.0 / s;
+    double err = 0; int acc = 0;
+    for (int i = 0; i < 3; i++) {
+      const double adj = k[i] * s * 256.0 + err;
+      const int v = cv_round(adj);
+      err = adj - v; h->taps[i] = v; acc += v;
+    }
+    h->taps[3] = 256 - 2 * acc;
+  }
+  DeviceGuard g(device_id);
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate"); }
+  *out = h;
+  return ORBHIP_OK;
+}
+
+void orb_extractor_destroy(OrbExtractor* h) {
+  if (!h) return;
+  DeviceGuard g(h->device);
+  hipStreamSynchronize(h->stream);
+  free_plan_buffers(h);
+  hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_nout);
+  hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int orb_extractor_get_scale_tables(const OrbExtractor* h, float* scale, float* inv_scale, float* sigma2,
+                                   float* inv_sigma2) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  for (int i = 0; i < h->nlevels; i++) {
+    if (scale) scale[i] = h->sf[i];
+    if (inv_scale) inv_scale[i] = h->inv_sf[i];
+    if (sigma2) sigma2[i] = h->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = h->inv_sigma2[i];
+  }
+  return h->nlevels;
+}
+
+int orb_extractor_get_level_quotas(const OrbExtractor* h, int* quotas, int* umax) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  if (quotas) for (int i = 0; i < h->nlevels; i++) quotas[i] = h->quota[i];
+  if (umax) for (int i = 0; i < 16; i++) umax[i] = h->umax[i];
+  return h->nlevels;
+}
+
+int orb_extractor_max_keypoints(OrbExtractor* h, int rows, int cols) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  Plan P; std::vector<XTab> xt; std::vector<YTab> yt; std::vector<FastItem> fi; std::vector<BlurItem> bi;
+  int rc = build_plan(h, rows, cols, P, xt, yt, fi, bi);
+  if (rc != ORBHIP_OK) return rc;
+  return P.sel_total;
+}
+
+int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_images, int rows, int cols,
+                             size_t stride, size_t frame_stride, int max_kp, OrbKeyPoint* d_keypoints,
+                             uint8_t* d_descriptors, int* d_n_out, void* stream) {
+  if (!h || !d_n_out) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if (n_frames <= 0) return ORBHIP_OK;
+  if (rows <= 0 || cols <= 0) {  // empty image: the reference returns without touching its outputs
+    DeviceGuard g(h->device);
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    ORB_HIP_CHECK(hipMemsetAsync(d_n_out, 0, sizeof(int) * n_frames, st));
+    return ORBHIP_OK;
+  }
+  if (!d_images || !d_keypoints || !d_descriptors || max_kp <= 0 || stride < (size_t)cols) {
+    set_error("null buffer, max_kp <= 0 or stride < cols"); return ORBHIP_ERR_ARG;
+  }
+  DeviceGuard g(h->device);
+  int rc = ensure_plan(h, rows, cols, n_frames);
+  if (rc != ORBHIP_OK) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  return enqueue(h, n_frames, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out, st);
+}
+
+int orb_extractor_sync(OrbExtractor* h) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  DeviceGuard g(h->device);
+  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return ORBHIP_OK;
+}
+
+int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int rows, int cols, size_t stride,
+                      size_t frame_stride, int max_kp, OrbKeyPoint* keypoints, uint8_t* descriptors, int* n_out) {
+  if (!h || !n_out) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if (n_frames <= 0) return ORBHIP_OK;
+  if (rows <= 0 || cols <= 0) { for (int k = 0; k < n_frames; k++) n_out[k] = 0; return ORBHIP_OK; }
+  if (!images || !keypoints || !descriptors || max_kp <= 0 || stride < (size_t)cols) {
+    set_error("null buffer, max_kp <= 0 or stride < cols"); return ORBHIP_ERR_ARG;
+  }
+  DeviceGuard g(h->device);
+  int rc = ensure_plan(h, rows, cols, n_frames);
+  if (rc != ORBHIP_OK) return rc;
+  const size_t img_bytes = (size_t)rows * cols * n_frames;
+  if (img_bytes > h->d_img_bytes) {
+    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+    hipFree(h->d_img); h->d_img = nullptr; h->d_img_bytes = 0;
+    ORB_HIP_CHECK(hipMalloc(&h->d_img, img_bytes));
+    h->d_img_bytes = img_bytes;
+  }
+  const size_t need = (size_t)n_frames * max_kp;
+  if (need > h->out_cap || n_frames > h->out_frames) {
+    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+    hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_nout);
+    h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->out_cap = 0; h->out_frames = 0;
+    ORB_HIP_CHECK(hipMalloc(&h->d_kps, sizeof(OrbKeyPoint) * need));
+    ORB_HIP_CHECK(hipMalloc(&h->d_desc, 32 * need));
+    ORB_HIP_CHECK(hipMalloc(&h->d_nout, sizeof(int) * n_frames));
+    h->out_cap = need; h->out_frames = n_frames;
+  }
+  hipStream_t st = h->stream;
+  for (int k = 0; k < n_frames; k++)
+    ORB_HIP_CHECK(hipMemcpy2DAsync(h->d_img + (size_t)k * rows * cols, cols, images + (size_t)k * frame_stride, stride,
+                                   cols, rows, hipMemcpyHostToDevice, st));
+  rc = enqueue(h, n_frames, h->d_img, cols, (size_t)rows * cols, max_kp, h->d_kps, h->d_desc, h->d_nout, st);
+  if (rc != ORBHIP_OK) return rc;
+  ORB_HIP_CHECK(hipMemcpyAsync(n_out, h->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, st));
+  ORB_HIP_CHECK(hipStreamSynchronize(st));
+  int status = ORBHIP_OK;
+  for (int k = 0; k < n_frames; k++) {
+    const int n = std::min(n_out[k], max_kp);
+    if (n_out[k] > max_kp) { set_error("max_kp too small: a frame produced " + std::to_string(n_out[k]) + " keypoints"); status = ORBHIP_ERR_CAPACITY; }
+    if (n > 0) {
+      ORB_HIP_CHECK(hipMemcpyAsync(keypoints + (size_t)k * max_kp, h->d_kps + (size_t)k * max_kp, sizeof(OrbKeyPoint) * n, hipMemcpyDeviceToHost, st));
+      ORB_HIP_CHECK(hipMemcpyAsync(descriptors + (size_t)k * max_kp * 32, h->d_desc + (size_t)k * max_kp * 32, 32 * (size_t)n, hipMemcpyDeviceToHost, st));
+    }
+  }
+  ORB_HIP_CHECK(hipStreamSynchronize(st));
+  return status;
+}
+
+int orb_extract(OrbExtractor* h, const uint8_t* image, int rows, int cols, size_t stride, int max_kp,
+                OrbKeyPoint* keypoints, uint8_t* descriptors, int* n_out) {
+  return orb_extract_batch(h, 1, image, rows, cols, stride, 0, max_kp, keypoints, descriptors, n_out);
+}
+
+static int check_frame_level(OrbExtractor* h, int frame, int level) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  if (!h->have_plan || h->last_frames == 0) { set_error("no extraction has run yet"); return ORBHIP_ERR_ARG; }
+  if (frame < 0 || frame >= h->last_frames || level < 0 || level >= h->nlevels) { set_error("frame or level out of range"); return ORBHIP_ERR_ARG; }
+  return ORBHIP_OK;
+}
+
+static int copy_level(OrbExtractor* h, const uint8_t* buf, int frame, int level, int padded, uint8_t* dst,
+                      size_t dst_stride, int* width, int* height) {
+  int rc = check_frame_level(h, frame, level);
+  if (rc != ORBHIP_OK) return rc;
+  const LevelGeom& L = h->plan.lv[level];
+  const int w = padded ? L.w + 2 * kEdge : L.w, hh = padded ? L.h + 2 * kEdge : L.h;
+  if (width) *width = w;
+  if (height) *height = hh;
+  if (!dst) return ORBHIP_OK;
+  if (dst_stride < (size_t)w) { set_error("dst_stride too small"); return ORBHIP_ERR_ARG; }
+  DeviceGuard g(h->device);
+  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const uint8_t* src = buf + (size_t)frame * h->plan.slab + L.off +
+                       (padded ? (size_t)(kXOff - kEdge) : (size_t)kEdge * L.pitch + kXOff);
+  ORB_HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.pitch, w, hh, hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_get_pyramid_level(OrbExtractor* h, int frame, int level, int padded, uint8_t* dst, size_t dst_stride,
+                          int* width, int* height) {
+  return copy_level(h, h ? h->d_pyr : nullptr, frame, level, padded, dst, dst_stride, width, height);
+}
+
+int orb_get_blurred_level(OrbExtractor* h, int frame, int level, uint8_t* dst, size_t dst_stride, int* width,
+                          int* height) {
+  return copy_level(h, h ? h->d_blur : nullptr, frame, level, 0, dst, dst_stride, width, height);
+}
+
+static int fetch_points(OrbExtractor* h, const uint32_t* d_arr, int per_frame, int off, const int* d_cnt, int frame,
+                        int level, std::vector<uint32_t>& out) {
+  int rc = check_frame_level(h, frame, level);
+  if (rc != ORBHIP_OK) return rc;
+  DeviceGuard g(h->device);
+  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  int n = 0;
+  ORB_HIP_CHECK(hipMemcpy(&n, d_cnt + frame * h->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+  out.resize(n);
+  if (n) ORB_HIP_CHECK(hipMemcpy(out.data(), d_arr + (size_t)frame * per_frame + off, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_get_fast_candidates(OrbExtractor* h, int frame, int level, int max_n, float* xyr) {
+  std::vector<uint32_t> v;
+  int rc = check_frame_level(h, frame, level);
+  if (rc != ORBHIP_OK) return rc;
+  const LevelGeom& L = h->plan.lv[level];
+  rc = fetch_points(h, h->d_cand, h->plan.cand_total, L.cand_off, h->d_cand_cnt, frame, level, v);
+  if (rc != ORBHIP_OK) return rc;
+  if ((int)v.size() > L.cand_cap) v.resize(L.cand_cap);
+  // workgroups append in arbitrary order; restore the reference's order:
+  // cell row, cell column, then raster order inside the cell
+  auto key = [&](uint32_t p) {
+    const int x = p & kCoordMask, y = (p >> kCoordBits) & kCoordMask;
+    return ((uint64_t)((y - 3) / L.hCell) << 40) | ((uint64_t)((x - 3) / L.wCell) << 28) | ((uint64_t)y << 14) | (uint64_t)x;
+  };
+  std::sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+  const int n = (int)v.size();
+  for (int i = 0; i < std::min(n, max_n); i++) {
+    xyr[3 * i] = (float)(v[i] & kCoordMask);
+    xyr[3 * i + 1] = (float)((v[i] >> kCoordBits) & kCoordMask);
+    xyr[3 * i + 2] = (float)(v[i] >> 24);
+  }
+  return n;
+}
+
+int orb_get_level_keypoints(OrbExtractor* h, int frame, int level, int max_n, float* xyr) {
+  std::vector<uint32_t> v;
+  int rc = check_frame_level(h, frame, level);
+  if (rc != ORBHIP_OK) return rc;
+  const LevelGeom& L = h->plan.lv[level];
+  rc = fetch_points(h, h->d_sel, h->plan.sel_total, L.sel_off, h->d_sel_cnt, frame, level, v);
+  if (rc != ORBHIP_OK) return rc;
+  const int n = (int)v.size();
+  for (int i = 0; i < std::min(n, max_n); i++) {
+    xyr[3 * i] = (float)((v[i] & kCoordMask) + kBorder);
+    xyr[3 * i + 1] = (float)(((v[i] >> kCoordBits) & kCoordMask) + kBorder);
+    xyr[3 * i + 2] = (float)(v[i] >> 24);
+  }
+  return n;
+}
+
+}  // extern "C"

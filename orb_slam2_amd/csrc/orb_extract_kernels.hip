@@ -1,0 +1,735 @@
+// HIP kernels of the ORB extractor for gfx950 (MI355X): pyramid, cell-wise FAST,
+// quad-tree keypoint distribution, 7x7 blur, orientation + rBRIEF.
+//
+// Every kernel works on a batch: blockIdx.y (or .z) is the frame.  Integer stages
+// are bit-exact restatements of the OpenCV arithmetic the reference calls; float
+// stages use _rn intrinsics so that no multiply-add is contracted.
+#include "orb_common.h"
+
+namespace orbhip {
+
+__constant__ int8_t c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+// Half-widths of the rows of the radius-15 orientation disc (reference
+// src/ORBextractor.cc:544-572 evaluates to these values; checked on the host at start-up).
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ int refl101(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * n - 2 - i : i;
+}
+
+// ---------------------------------------------------------------------------
+// Pyramid.  One thread writes 4 consecutive bytes of a padded slab row.
+// Level 0: copy of the input with a 19-px BORDER_REFLECT_101 frame
+// (reference src/ORBextractor.cc:1406-1408).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restrict__ img, size_t stride,
+                                                         size_t frame_stride, uint8_t* __restrict__ pyr,
+                                                         unsigned long long slab, LevelGeom L) {
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c4 >= L.pitch) return;
+  const int row = blockIdx.y;  // padded row
+  const int f = blockIdx.z;
+  const int iy = refl101(row - kEdge, L.h);
+  const uint8_t* S = img + (size_t)f * frame_stride + (size_t)iy * stride;
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int px = c4 + k - kXOff;
+    if (px >= -kEdge && px < L.w + kEdge) out |= (uint32_t)S[refl101(px, L.w)] << (8 * k);
+  }
+  *reinterpret_cast<uint32_t*>(pyr + (size_t)f * slab + L.off + (size_t)row * L.pitch + c4) = out;
+}
+
+// Level l >= 1: cv::resize(INTER_LINEAR, 8U fixed point) of level l-1's un-padded
+// pixels, then the reflected frame of level l itself
+// (reference src/ORBextractor.cc:1367-1389).  Frame pixels are recomputed from the
+// mirrored coordinate instead of being copied, so one pass writes the whole slab row.
+__global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ pyr, unsigned long long slab,
+                                                         LevelGeom Ls, LevelGeom Ld,
+                                                         const XTab* __restrict__ xt,
+                                                         const YTab* __restrict__ yt) {
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c4 >= Ld.pitch) return;
+  const int row = blockIdx.y;
+  const int f = blockIdx.z;
+  const int iy = refl101(row - kEdge, Ld.h);
+  const YTab ty = yt[iy];
+  const uint8_t* src = pyr + (size_t)f * slab + Ls.off + kXOff;
+  const uint8_t* S0 = src + (size_t)(ty.sy0 + kEdge) * Ls.pitch;
+  const uint8_t* S1 = src + (size_t)(ty.sy1 + kEdge) * Ls.pitch;
+  const int b0 = ty.b0, b1 = ty.b1;
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int px = c4 + k - kXOff;
+    if (px >= -kEdge && px < Ld.w + kEdge) {
+      const XTab tx = xt[refl101(px, Ld.w)];
+      const int sx = tx.sx;
+      const int sx1 = min(sx + 1, Ls.w - 1);
+      const int r0 = S0[sx] * tx.a0 + S0[sx1] * tx.a1;
+      const int r1 = S1[sx] * tx.a0 + S1[sx1] * tx.a1;
+      int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      v = min(max(v, 0), 255);
+      out |= (uint32_t)v << (8 * k);
+    }
+  }
+  *reinterpret_cast<uint32_t*>(pyr + (size_t)f * slab + Ld.off + (size_t)row * Ld.pitch + c4) = out;
+}
+
+// ---------------------------------------------------------------------------
+// FAST-9/16 per cell with the iniThFAST -> minThFAST fallback and cell-local
+// 3x3 non-maximum suppression (reference src/ORBextractor.cc:1077-1146 calling
+// cv::FAST).  A workgroup stages a run of cells of one cell row in LDS.
+//
+// For a pixel with centre c and ring p[0..15], let d[k] = c - p[k],
+//   A = max_k min(d[k..k+8]),  B = max_k min(-d[k..k+8]),  V = max(A, B).
+// The pixel is a corner at threshold t iff V > t, and OpenCV's corner score is
+// then V - 1; so one V map serves both thresholds.
+// ---------------------------------------------------------------------------
+constexpr int F_THREADS = 256;
+constexpr int F_USEW = 256;   // widest run of cell interiors per workgroup
+constexpr int F_PITCH = 272;  // LDS row pitch: F_USEW + 6 halo + 3 alignment, rounded up
+constexpr int F_MAXH = 66;    // tallest cell view (hCell <= 59, + 6)
+constexpr int F_MAXCELLS = 16;
+constexpr int F_BAND = 2048;
+
+__device__ __forceinline__ int fast_v(const uint8_t* p /* centre in LDS */) {
+  const int c = p[0];
+  int d[16];
+  d[0] = c - p[3 * F_PITCH];
+  d[1] = c - p[3 * F_PITCH + 1];
+  d[2] = c - p[2 * F_PITCH + 2];
+  d[3] = c - p[F_PITCH + 3];
+  d[4] = c - p[3];
+  d[5] = c - p[-F_PITCH + 3];
+  d[6] = c - p[-2 * F_PITCH + 2];
+  d[7] = c - p[-3 * F_PITCH + 1];
+  d[8] = c - p[-3 * F_PITCH];
+  d[9] = c - p[-3 * F_PITCH - 1];
+  d[10] = c - p[-2 * F_PITCH - 2];
+  d[11] = c - p[-F_PITCH - 3];
+  d[12] = c - p[-3];
+  d[13] = c - p[F_PITCH - 3];
+  d[14] = c - p[2 * F_PITCH - 2];
+  d[15] = c - p[3 * F_PITCH - 1];
+  int mn[16], mx[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn[k] = min(d[k], d[(k + 1) & 15]);
+    mx[k] = max(d[k], d[(k + 1) & 15]);
+  }
+  int mn4[16], mx4[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn4[k] = min(mn[k], mn[(k + 2) & 15]);
+    mx4[k] = max(mx[k], mx[(k + 2) & 15]);
+  }
+  int a = -256, b = 256;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+    const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+    a = max(a, m9);
+    b = min(b, x9);
+  }
+  return max(a, -b);
+}
+
+__global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
+                                                         const FastItem* __restrict__ items,
+                                                         uint32_t* __restrict__ cand_all,
+                                                         int* __restrict__ cand_cnt, int iniTh, int minTh) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[F_MAXH * F_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t s_v[F_MAXH * F_PITCH];
+  __shared__ uint16_t s_list[F_BAND];
+  __shared__ int s_cnt[F_MAXCELLS];
+  __shared__ int s_nlist, s_total, s_base, s_emit;
+
+  const FastItem item = items[blockIdx.x];
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x;
+  const LevelGeom& L = P.lv[item.level];
+  const int wCell = L.wCell, hCell = L.hCell;
+  const int iniY = kBorder + item.row * hCell;
+  const int maxY = min(iniY + hCell + 6, L.maxBY);
+  const int xb = kBorder + item.j0 * wCell;
+  const int xe = min(kBorder + (item.j0 + item.ncells) * wCell + 6, L.maxBX);
+  const int tw = xe - xb, th = maxY - iniY;
+  const int wi = tw - 6, hi = th - 6;  // interior (pixels that can be corners)
+  if (wi <= 0 || hi <= 0) return;      // uniform: a view shorter than 7 rows yields nothing
+
+  // stage the view, dword-aligned on the slab
+  const int a0 = (xb + kXOff) & ~3;
+  const int shift = (xb + kXOff) - a0;
+  const int ndw = (shift + tw + 3) >> 2;
+  const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(iniY + kEdge) * L.pitch + a0;
+  for (int i = tid; i < th * ndw; i += F_THREADS) {
+    const int r = i / ndw, c = i - r * ndw;
+    *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * c]) =
+        *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * c);
+  }
+  for (int i = tid; i < (F_MAXH * F_PITCH) / 4; i += F_THREADS) reinterpret_cast<uint32_t*>(s_v)[i] = 0;
+  if (tid < F_MAXCELLS) s_cnt[tid] = 0;
+  __syncthreads();
+
+  const int npix = wi * hi;
+  unsigned cellmask = (1u << item.ncells) - 1;  // cells to (re)compute in this pass
+  for (int pass = 0; pass < 2; pass++) {
+    const int t = pass == 0 ? iniTh : minTh;
+    // ---- V map for the masked cells, in bands: quick reject -> compact -> full test
+    for (int band = 0; band < npix; band += F_BAND) {
+      if (tid == 0) s_nlist = 0;
+      __syncthreads();
+      for (int i = band + tid; i < min(band + F_BAND, npix); i += F_THREADS) {
+        const int y = i / wi, x = i - y * wi;
+        bool ok = false;
+        if ((cellmask >> (x / wCell)) & 1u) {
+          const uint8_t* p = &s_img[(y + 3) * F_PITCH + x + 3 + shift];
+          const int c = p[0];
+          const int p0 = p[3 * F_PITCH], p4 = p[3], p8 = p[-3 * F_PITCH], p12 = p[-3];
+          const int hi_t = c + t, lo_t = c - t;
+          const bool b0 = p0 > hi_t, b4 = p4 > hi_t, b8 = p8 > hi_t, b12 = p12 > hi_t;
+          const bool d0 = p0 < lo_t, d4 = p4 < lo_t, d8 = p8 < lo_t, d12 = p12 < lo_t;
+          // any 9 contiguous ring pixels contain two adjacent compass points
+          ok = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (d0 & d4) | (d4 & d8) | (d8 & d12) | (d12 & d0);
+        }
+        if (ok) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(i - band);
+      }
+      __syncthreads();
+      const int nl = s_nlist;
+      for (int k = tid; k < nl; k += F_THREADS) {
+        const int i = band + s_list[k];
+        const int y = i / wi, x = i - y * wi;
+        const int off = (y + 3) * F_PITCH + x + 3 + shift;
+        const int v = fast_v(&s_img[off]);
+        s_v[off] = (uint8_t)(v > t ? v : 0);
+      }
+      __syncthreads();
+    }
+    // ---- cell-local NMS: count per cell
+    for (int i = tid; i < npix; i += F_THREADS) {
+      const int y = i / wi, x = i - y * wi;
+      const int cj = x / wCell;
+      if (!((cellmask >> cj) & 1u)) continue;
+      const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + 3 + shift];
+      const int v = q[0];
+      if (v < 2) continue;
+      const int xc = x - cj * wCell;
+      const bool hasL = xc > 0, hasR = (xc < wCell - 1);
+      bool keep = v > q[-F_PITCH] && v > q[F_PITCH];
+      if (hasL) keep = keep && v > q[-1] && v > q[-F_PITCH - 1] && v > q[F_PITCH - 1];
+      if (hasR) keep = keep && v > q[1] && v > q[-F_PITCH + 1] && v > q[F_PITCH + 1];
+      if (keep) atomicAdd(&s_cnt[cj], 1);
+    }
+    __syncthreads();
+    if (pass == 1) break;
+    unsigned need = 0;
+    for (int c = 0; c < item.ncells; c++)
+      if (s_cnt[c] == 0) need |= 1u << c;
+    if (need == 0) break;  // uniform
+    cellmask = need;
+    // clear the V columns of the cells that get the lower threshold
+    for (int i = tid; i < npix; i += F_THREADS) {
+      const int y = i / wi, x = i - y * wi;
+      if ((need >> (x / wCell)) & 1u) s_v[(y + 3) * F_PITCH + x + 3 + shift] = 0;
+    }
+    __syncthreads();
+  }
+
+  // ---- reserve output range, emit
+  if (tid == 0) {
+    int tot = 0;
+    for (int c = 0; c < item.ncells; c++) tot += s_cnt[c];
+    s_total = tot;
+    s_emit = 0;
+    s_base = tot ? atomicAdd(&cand_cnt[f * P.nlevels + item.level], tot) : 0;
+  }
+  __syncthreads();
+  if (s_total == 0) return;
+  uint32_t* out = cand_all + (size_t)f * P.cand_total + L.cand_off;
+  const int gbase = s_base;
+  for (int i = tid; i < npix; i += F_THREADS) {
+    const int y = i / wi, x = i - y * wi;
+    const int cj = x / wCell;
+    const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + 3 + shift];
+    const int v = q[0];
+    if (v < 2) continue;
+    const int xc = x - cj * wCell;
+    const bool hasL = xc > 0, hasR = (xc < wCell - 1);
+    bool keep = v > q[-F_PITCH] && v > q[F_PITCH];
+    if (hasL) keep = keep && v > q[-1] && v > q[-F_PITCH - 1] && v > q[F_PITCH - 1];
+    if (hasR) keep = keep && v > q[1] && v > q[-F_PITCH + 1] && v > q[F_PITCH + 1];
+    if (keep) {
+      const int slot = gbase + atomicAdd(&s_emit, 1);
+      const int xr = xb + 3 + x - kBorder, yr = iniY + 3 + y - kBorder;
+      if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Quad-tree keypoint distribution (reference src/ORBextractor.cc:690-1036 and
+// ExtractorNode::DivideNode :604-676), one workgroup per (level, frame).
+//
+// The reference keeps a std::list of nodes, pushes children to the front and
+// finally walks the list.  Restated without the list:
+//  * every node carries a key that grows with creation time (roots: reversed index),
+//    so the list order is "descending key";
+//  * a full pass splits every node that holds more than one point; an "ordered"
+//    round splits them in (count, key)-descending order and stops at the first
+//    split that brings the node total to N -- which nodes get split follows from a
+//    prefix sum of (children - 1) over that order;
+//  * points never move: each carries the slot of its current node.
+// Ties of the reference's sort of pair<count, node*> are resolved as if node
+// addresses grew with allocation order (later-created node first).
+// ---------------------------------------------------------------------------
+constexpr int OT_THREADS = 512;
+constexpr int OT_MAXS = 1024;  // node slots
+
+struct OtShared {
+  short x0[OT_MAXS], x1[OT_MAXS], y0[OT_MAXS], y1[OT_MAXS];
+  int count[OT_MAXS];
+  int key[OT_MAXS];
+  int ccount[OT_MAXS * 4];
+  short cslot[OT_MAXS * 4];
+  unsigned long long skey[OT_MAXS];
+  short elist[OT_MAXS];
+  short order[OT_MAXS];
+  int cumg[OT_MAXS];
+  int cumc[OT_MAXS];
+  unsigned char split[OT_MAXS];
+  int vars[16];
+};
+enum { V_SIZE = 0, V_NSLOTS, V_NEXTSEQ, V_MODE, V_FINISH, V_NE, V_NEWEXP, V_PN, V_GROW, V_NCHILD };
+
+__global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __restrict__ cand_all,
+                                                            const int* __restrict__ cand_cnt,
+                                                            uint32_t* __restrict__ pnode_all,
+                                                            uint32_t* __restrict__ sel_all,
+                                                            int* __restrict__ sel_cnt, Plan P) {
+  __shared__ OtShared S;
+  const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const LevelGeom& L = P.lv[l];
+  const uint32_t* pts = cand_all + (size_t)f * P.cand_total + L.cand_off;
+  uint32_t* pn = pnode_all + (size_t)f * P.cand_total + L.cand_off;
+  uint32_t* sel = sel_all + (size_t)f * P.sel_total + L.sel_off;
+  const int n = min(cand_cnt[f * P.nlevels + l], L.cand_cap);
+  const int N = L.quota;
+  const int nIni = L.nIni;
+  const float hX = L.hX;
+
+  for (int s = tid; s < OT_MAXS; s += OT_THREADS) S.count[s] = 0;
+  if (tid < nIni) {
+    S.x0[tid] = (short)(int)__fmul_rn(hX, (float)tid);
+    S.x1[tid] = (short)(int)__fmul_rn(hX, (float)(tid + 1));
+    S.y0[tid] = 0;
+    S.y1[tid] = (short)(L.maxBY - kBorder);
+    S.key[tid] = nIni - 1 - tid;
+  }
+  __syncthreads();
+  for (int p = tid; p < n; p += OT_THREADS) {
+    const int x = pts[p] & kCoordMask;
+    int r = (int)__fdiv_rn((float)x, hX);
+    r = min(max(r, 0), nIni - 1);
+    pn[p] = (uint32_t)r;
+    atomicAdd(&S.count[r], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int sz = 0;
+    for (int r = 0; r < nIni; r++) sz += S.count[r] > 0;
+    S.vars[V_SIZE] = sz;
+    S.vars[V_NSLOTS] = nIni;
+    S.vars[V_NEXTSEQ] = nIni;
+    S.vars[V_MODE] = 0;
+    S.vars[V_FINISH] = 0;
+  }
+  __syncthreads();
+
+  while (true) {
+    const int finish = S.vars[V_FINISH];
+    const int nslots = S.vars[V_NSLOTS], size = S.vars[V_SIZE], mode = S.vars[V_MODE];
+    const int nextseq = S.vars[V_NEXTSEQ];
+    __syncthreads();
+    if (finish) break;
+    if (tid == 0) { S.vars[V_NE] = 0; S.vars[V_NEWEXP] = 0; }
+    __syncthreads();
+    // 1. nodes that can be split
+    for (int s = tid; s < nslots; s += OT_THREADS) {
+      S.split[s] = 0;
+      if (S.count[s] > 1) {
+        S.elist[atomicAdd(&S.vars[V_NE], 1)] = (short)s;
+        S.ccount[4 * s] = 0; S.ccount[4 * s + 1] = 0; S.ccount[4 * s + 2] = 0; S.ccount[4 * s + 3] = 0;
+      }
+    }
+    __syncthreads();
+    const int E = S.vars[V_NE];
+    // 2. quadrant of every point of such a node (DivideNode's point loop)
+    for (int p = tid; p < n; p += OT_THREADS) {
+      const int s = pn[p] & 0xFFFF;
+      if (S.count[s] > 1) {
+        const uint32_t v = pts[p];
+        const int x = v & kCoordMask, y = (v >> kCoordBits) & kCoordMask;
+        const int hx = (S.x1[s] - S.x0[s] + 1) >> 1, hy = (S.y1[s] - S.y0[s] + 1) >> 1;
+        const int q = (x < S.x0[s] + hx ? 0 : 1) + (y < S.y0[s] + hy ? 0 : 2);
+        pn[p] = (uint32_t)s | ((uint32_t)q << 16);
+        atomicAdd(&S.ccount[4 * s + q], 1);
+      }
+    }
+    __syncthreads();
+    // 3. processing order: rank by key (full pass) or by (count, key) (ordered round), descending
+    for (int i = tid; i < E; i += OT_THREADS) {
+      const int s = S.elist[i];
+      S.skey[i] = mode == 0 ? (unsigned long long)(unsigned)S.key[s]
+                            : (((unsigned long long)(unsigned)S.count[s] << 32) | (unsigned)S.key[s]);
+    }
+    __syncthreads();
+    for (int i = tid; i < E; i += OT_THREADS) {
+      const unsigned long long k = S.skey[i];
+      int r = 0;
+      for (int j = 0; j < E; j++) r += S.skey[j] > k;
+      const int s = S.elist[i];
+      S.order[r] = (short)s;
+      const int c = (S.ccount[4 * s] > 0) + (S.ccount[4 * s + 1] > 0) + (S.ccount[4 * s + 2] > 0) + (S.ccount[4 * s + 3] > 0);
+      S.cumg[r] = c - 1;
+      S.cumc[r] = c;
+    }
+    __syncthreads();
+    // 4./5. prefix sums over the processing order; in an ordered round stop at the
+    // first split that reaches N nodes
+    if (tid < 64) {
+      int cg = 0, cc = 0, pn_ = -1;
+      for (int base = 0; base < E; base += 64) {
+        const int i = base + tid;
+        int g = i < E ? S.cumg[i] : 0, c = i < E ? S.cumc[i] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int g2 = __shfl_up(g, o), c2 = __shfl_up(c, o);
+          if (tid >= o) { g += g2; c += c2; }
+        }
+        g += cg; c += cc;
+        if (i < E) { S.cumg[i] = g; S.cumc[i] = c; }
+        if (mode == 1 && pn_ < 0) {
+          const unsigned long long hit = __ballot(i < E && size + g >= N);
+          if (hit) pn_ = base + __ffsll((long long)hit);  // index of first hit + 1
+        }
+        cg = __shfl(g, 63); cc = __shfl(c, 63);
+      }
+      if (tid == 0) {
+        const int Pn = pn_ < 0 ? E : pn_;
+        S.vars[V_PN] = Pn;
+        S.vars[V_GROW] = Pn ? S.cumg[Pn - 1] : 0;
+        S.vars[V_NCHILD] = Pn ? S.cumc[Pn - 1] : 0;
+      }
+    }
+    __syncthreads();
+    const int Pn = S.vars[V_PN];
+    // 6. split the first Pn nodes of the order
+    for (int r = tid; r < Pn; r += OT_THREADS) {
+      const int s = S.order[r];
+      const int X0 = S.x0[s], X1 = S.x1[s], Y0 = S.y0[s], Y1 = S.y1[s];
+      const int hx = (X1 - X0 + 1) >> 1, hy = (Y1 - Y0 + 1) >> 1;
+      const int gbase = r ? S.cumg[r - 1] : 0, cbase = r ? S.cumc[r - 1] : 0;
+      int cc[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) cc[q] = S.ccount[4 * s + q];
+      S.split[s] = 1;
+      int k = 0, newexp = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (cc[q] > 0) {
+          const int slot = k == 0 ? s : nslots + gbase + (k - 1);
+          S.cslot[4 * s + q] = (short)slot;
+          S.x0[slot] = (short)((q & 1) ? X0 + hx : X0);
+          S.x1[slot] = (short)((q & 1) ? X1 : X0 + hx);
+          S.y0[slot] = (short)((q & 2) ? Y0 + hy : Y0);
+          S.y1[slot] = (short)((q & 2) ? Y1 : Y0 + hy);
+          S.count[slot] = cc[q];
+          S.key[slot] = nextseq + cbase + k;
+          newexp += cc[q] > 1;
+          k++;
+        }
+      }
+      if (newexp) atomicAdd(&S.vars[V_NEWEXP], newexp);
+    }
+    __syncthreads();
+    // 7. move the points of split nodes to their child
+    for (int p = tid; p < n; p += OT_THREADS) {
+      const uint32_t w = pn[p];
+      const int s = w & 0xFFFF;
+      if (S.split[s]) pn[p] = (uint32_t)(unsigned short)S.cslot[4 * s + (w >> 16)];
+    }
+    __syncthreads();
+    // 8. loop control (src/ORBextractor.cc:891-897, 911, 992-993)
+    if (tid == 0) {
+      const int newsize = size + S.vars[V_GROW];
+      S.vars[V_SIZE] = newsize;
+      S.vars[V_NSLOTS] = nslots + S.vars[V_GROW];
+      S.vars[V_NEXTSEQ] = nextseq + S.vars[V_NCHILD];
+      if (newsize >= N || newsize == size) S.vars[V_FINISH] = 1;
+      else if (mode == 0 && newsize + 3 * S.vars[V_NEWEXP] > N) S.vars[V_MODE] = 1;
+    }
+    __syncthreads();
+  }
+
+  // best point of every node: highest response, first in the reference's candidate
+  // order (cell row, cell column, y, x) on ties (src/ORBextractor.cc:1007-1032)
+  const int nslots = S.vars[V_NSLOTS];
+  for (int s = tid; s < nslots; s += OT_THREADS) S.skey[s] = 0;
+  __syncthreads();
+  for (int p = tid; p < n; p += OT_THREADS) {
+    const int s = pn[p] & 0xFFFF;
+    const uint32_t v = pts[p];
+    const int x = v & kCoordMask, y = (v >> kCoordBits) & kCoordMask;
+    const unsigned long long canon =
+        ((unsigned long long)(((y - 3) / L.hCell) * 256 + (x - 3) / L.wCell) << 24) | ((unsigned)y << 12) | (unsigned)x;
+    const unsigned long long k = ((unsigned long long)(v >> 24) << 40) | (((1ull << 40) - 1) - canon);
+    atomicMax(&S.skey[s], k);
+  }
+  __syncthreads();
+  for (int s = tid; s < nslots; s += OT_THREADS) {
+    if (S.count[s] <= 0) continue;
+    const int k = S.key[s];
+    int r = 0;
+    for (int j = 0; j < nslots; j++) r += (S.count[j] > 0) && (S.key[j] > k);
+    const unsigned long long b = S.skey[s];
+    const unsigned long long canon = ((1ull << 40) - 1) - (b & ((1ull << 40) - 1));
+    const uint32_t x = (uint32_t)(canon & 0xFFF), y = (uint32_t)((canon >> 12) & 0xFFF);
+    if (r < L.sel_cap) sel[r] = x | (y << kCoordBits) | ((uint32_t)(b >> 40) << 24);
+  }
+  if (tid == 0) sel_cnt[f * P.nlevels + l] = min(S.vars[V_SIZE], L.sel_cap);
+}
+
+// ---------------------------------------------------------------------------
+// cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101), 8-bit fixed-point path
+// (called at reference src/ORBextractor.cc:1300-1305).  Taps are 8.8 fixed point
+// and sum to 256; the row pass keeps 8.8, the column pass 16.16, result
+// (acc + 2^15) >> 16.  The padded pyramid already holds the reflected border.
+// ---------------------------------------------------------------------------
+constexpr int B_TW = 128, B_TH = 32, B_THREADS = 256;
+constexpr int B_INP = B_TW + 16;  // staged row bytes (tile + 8, rounded up)
+
+__global__ __launch_bounds__(B_THREADS) void blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                                         Plan P, const BlurItem* __restrict__ items, int t0, int t1,
+                                                         int t2, int t3) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_in[(B_TH + 6) * B_INP];
+  __shared__ __attribute__((aligned(16))) uint16_t s_h[(B_TH + 6) * B_TW];
+  const BlurItem it = items[blockIdx.x];
+  const int f = blockIdx.y, tid = threadIdx.x;
+  const LevelGeom& L = P.lv[it.level];
+  const int x0 = it.tx * B_TW, y0 = it.ty * B_TH;
+  const int tw = min(B_TW, L.w - x0), th = min(B_TH, L.h - y0);
+  const int tw4 = (tw + 3) >> 2;
+  // staged columns: level x in [x0 - 4, x0 - 4 + 4*ndw)
+  const int ndw = tw4 + 2;
+  const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(y0 - 3 + kEdge) * L.pitch + (x0 - 4 + kXOff);
+  for (int i = tid; i < (th + 6) * ndw; i += B_THREADS) {
+    const int r = i / ndw, c = i - r * ndw;
+    *reinterpret_cast<uint32_t*>(&s_in[r * B_INP + 4 * c]) =
+        *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * c);
+  }
+  __syncthreads();
+  for (int i = tid; i < (th + 6) * tw4; i += B_THREADS) {
+    const int r = i / tw4, c = i - r * tw4;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_in[r * B_INP + 4 * c]);
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    int b[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      b[k] = (w0 >> (8 * k)) & 0xFF;
+      b[4 + k] = (w1 >> (8 * k)) & 0xFF;
+      b[8 + k] = (w2 >> (8 * k)) & 0xFF;
+    }
+    uint16_t h[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      h[j] = (uint16_t)(t0 * (b[j + 1] + b[j + 7]) + t1 * (b[j + 2] + b[j + 6]) + t2 * (b[j + 3] + b[j + 5]) + t3 * b[j + 4]);
+    uint2 o;
+    o.x = h[0] | ((uint32_t)h[1] << 16);
+    o.y = h[2] | ((uint32_t)h[3] << 16);
+    *reinterpret_cast<uint2*>(&s_h[r * B_TW + 4 * c]) = o;
+  }
+  __syncthreads();
+  uint8_t* dst = blur + (size_t)f * P.slab + L.off + (size_t)(y0 + kEdge) * L.pitch + x0 + kXOff;
+  for (int i = tid; i < th * tw4; i += B_THREADS) {
+    const int r = i / tw4, c = i - r * tw4;
+    uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const uint2 v = *reinterpret_cast<const uint2*>(&s_h[(r + k) * B_TW + 4 * c]);
+      const int t = k == 0 || k == 6 ? t0 : (k == 1 || k == 5 ? t1 : (k == 2 || k == 4 ? t2 : t3));
+      acc[0] += t * (v.x & 0xFFFF);
+      acc[1] += t * (v.x >> 16);
+      acc[2] += t * (v.y & 0xFFFF);
+      acc[3] += t * (v.y >> 16);
+    }
+    uint32_t o = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o |= min((acc[j] + 32768u) >> 16, 255u) << (8 * j);
+    *reinterpret_cast<uint32_t*>(dst + (size_t)r * L.pitch + 4 * c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Orientation (IC_Angle, reference src/ORBextractor.cc:96-143, with
+// cv::fastAtan2) and steered BRIEF (computeOrbDescriptor, :155-206), one wavefront
+// per keypoint; also the epilogue of operator() (:1164-1179, 1323-1337).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float s = (float)(180.0 / 3.14159265358979323846);
+  const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
+  const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float eps = 2.2204460492503131e-16f;
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  } else {
+    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+  }
+  if (x < 0) a = __fsub_rn(180.f, a);
+  if (y < 0) a = __fsub_rn(360.f, a);
+  return a;
+}
+
+constexpr int D_THREADS = 256;
+
+__global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* __restrict__ pyr,
+                                                                const uint8_t* __restrict__ blur,
+                                                                const uint32_t* __restrict__ sel_all,
+                                                                const int* __restrict__ sel_cnt, Plan P,
+                                                                OrbKeyPoint* __restrict__ out_kps,
+                                                                uint8_t* __restrict__ out_desc,
+                                                                int* __restrict__ n_out, int max_kp) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * (D_THREADS / 64) + (threadIdx.x >> 6);  // slot in the per-frame selected array
+  const int* cnt = sel_cnt + f * P.nlevels;
+  if (k == 0 && lane == 0) {
+    int tot = 0;
+    for (int l = 0; l < P.nlevels; l++) tot += cnt[l];
+    n_out[f] = tot;
+  }
+  if (k >= P.sel_total) return;
+  int l = 0, before = 0;
+  while (l + 1 < P.nlevels && k >= P.lv[l + 1].sel_off) { before += cnt[l]; l++; }
+  const LevelGeom& L = P.lv[l];
+  const int i = k - L.sel_off;
+  if (i >= cnt[l]) return;
+  const int o = before + i;
+  if (o >= max_kp) return;
+  const uint32_t v = sel_all[(size_t)f * P.sel_total + k];
+  const int cx = (int)(v & kCoordMask) + kBorder, cy = (int)((v >> kCoordBits) & kCoordMask) + kBorder;
+  const size_t lvl = (size_t)f * P.slab + L.off + (size_t)(cy + kEdge) * L.pitch + cx + kXOff;
+
+  // intensity centroid: lane = 2*row + half
+  int m10 = 0, m01 = 0;
+  {
+    const int row = lane >> 1, half = lane & 1;
+    if (row < 31) {
+      const int vv = row - 15;
+      const int d = c_umax[vv < 0 ? -vv : vv];
+      const uint8_t* p = pyr + lvl + (ptrdiff_t)vv * L.pitch;
+      int sum = 0;
+      const int u0 = half ? 0 : -d, u1 = half ? d : -1;
+      for (int u = u0; u <= u1; u++) {
+        const int val = p[u];
+        m10 += u * val;
+        sum += val;
+      }
+      m01 = vv * sum;
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    m10 += __shfl_xor(m10, s);
+    m01 += __shfl_xor(m01, s);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // steered BRIEF on the blurred level
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float rad = __fmul_rn(angle, factorPI);
+  const float a = (float)cos((double)rad), b = (float)sin((double)rad);
+  const uint8_t* ctr = blur + lvl;
+  const int pitch = L.pitch;
+  unsigned long long bits[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int pr = lane + 64 * j;
+    const int px0 = c_pattern[4 * pr], py0 = c_pattern[4 * pr + 1];
+    const int px1 = c_pattern[4 * pr + 2], py1 = c_pattern[4 * pr + 3];
+    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn((float)px0, b), __fmul_rn((float)py0, a)));
+    const int q0 = __float2int_rn(__fsub_rn(__fmul_rn((float)px0, a), __fmul_rn((float)py0, b)));
+    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn((float)px1, b), __fmul_rn((float)py1, a)));
+    const int q1 = __float2int_rn(__fsub_rn(__fmul_rn((float)px1, a), __fmul_rn((float)py1, b)));
+    const int t0 = ctr[(ptrdiff_t)r0 * pitch + q0], t1 = ctr[(ptrdiff_t)r1 * pitch + q1];
+    bits[j] = __ballot(t0 < t1);
+  }
+  if (lane < 4) {
+    const unsigned long long w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+    reinterpret_cast<unsigned long long*>(out_desc + ((size_t)f * max_kp + o) * 32)[lane] = w;
+  }
+  if (lane == 0) {
+    OrbKeyPoint kp;
+    kp.x = l ? __fmul_rn((float)cx, L.scale) : (float)cx;
+    kp.y = l ? __fmul_rn((float)cy, L.scale) : (float)cy;
+    kp.size = L.kp_size;
+    kp.angle = angle;
+    kp.response = (float)(v >> 24);
+    kp.octave = l;
+    out_kps[(size_t)f * max_kp + o] = kp;
+  }
+}
+
+// ---- launchers --------------------------------------------------------------
+void launch_pyr_level0(const uint8_t* img, size_t stride, size_t frame_stride, uint8_t* pyr, const Plan& P,
+                       int nframes, hipStream_t st) {
+  const LevelGeom& L = P.lv[0];
+  dim3 grid((L.pitch / 4 + 255) / 256, L.h + 2 * kEdge, nframes);
+  hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L);
+}
+void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, const YTab* yt, int nframes,
+                       hipStream_t st) {
+  const LevelGeom& Ld = P.lv[level];
+  dim3 grid((Ld.pitch / 4 + 255) / 256, Ld.h + 2 * kEdge, nframes);
+  hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, st, pyr, P.slab, P.lv[level - 1], Ld, xt + Ld.xtab_off,
+                     yt + Ld.ytab_off);
+}
+void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, uint32_t* cand, int* cand_cnt,
+                 int iniTh, int minTh, int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(fast_kernel, dim3(nitems, nframes), dim3(F_THREADS), 0, st, pyr, P, items, cand, cand_cnt, iniTh,
+                     minTh);
+}
+void launch_octree(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel, int* sel_cnt,
+                   const Plan& P, int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(octree_kernel, dim3(P.nlevels, nframes), dim3(OT_THREADS), 0, st, cand, cand_cnt, pnode, sel,
+                     sel_cnt, P);
+}
+void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurItem* items, int nitems, const int* taps,
+                 int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(blur_kernel, dim3(nitems, nframes), dim3(B_THREADS), 0, st, pyr, blur, P, items, taps[0], taps[1],
+                     taps[2], taps[3]);
+}
+void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel, const int* sel_cnt, const Plan& P,
+                        OrbKeyPoint* kps, uint8_t* desc, int* n_out, int max_kp, int nframes, hipStream_t st) {
+  const int nb = (P.sel_total + (D_THREADS / 64) - 1) / (D_THREADS / 64);
+  hipLaunchKernelGGL(orient_desc_kernel, dim3(nb, nframes), dim3(D_THREADS), 0, st, pyr, blur, sel, sel_cnt, P, kps,
+                     desc, n_out, max_kp);
+}
+
+int fast_use_width() { return F_USEW; }
+int fast_max_cells() { return F_MAXCELLS; }
+int fast_max_view_h() { return F_MAXH; }
+int octree_max_slots() { return OT_MAXS; }
+int blur_tile_w() { return B_TW; }
+int blur_tile_h() { return B_TH; }
+
+}  // namespace orbhip
