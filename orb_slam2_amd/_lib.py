@@ -61,9 +61,6 @@ def lib():
     L.orb_get_blurred_level.argtypes = [vp, i, i, vp, sz, C.POINTER(i), C.POINTER(i)]
     L.orb_get_fast_candidates.argtypes = [vp, i, i, i, vp]
     L.orb_get_level_keypoints.argtypes = [vp, i, i, i, vp]
-    if not hasattr(L, "orb_knn2_bruteforce"):  # MATCHER-BIND (dev)
-        _lib = L
-        return L
     L.orb_hamming_distance_pairs.argtypes = [i, vp, vp, i, vp]
     L.orb_search_by_projection_frames.argtypes = (
         [i, i, i, i, vp, f, f, f, f, FrameBounds, vp, i] + [vp] * 13 + [f, i, vp, vp])

@@ -1,1 +1,812 @@
-// placeholder, replaced below
+// Hamming matching on gfx950: DescriptorDistance batches, brute-force kNN-2, and the
+// candidate scans of ORBmatcher::SearchByProjection / SearchForTriangulation.
+//
+// The reference matchers are greedy: a train keypoint taken by an earlier query is
+// skipped by later ones.  Each matcher kernel therefore has a parallel phase (every
+// query scans its candidates and keeps its few best, ordered exactly like the
+// reference's sequential scan would rank them) and a short ordered phase that
+// replays the reference's query order on those lists, 64 queries per step.
+#include <algorithm>
+#include <vector>
+
+#include "orb_common.h"
+
+namespace orbhip {
+
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher.cc:41-43
+constexpr int GRID_COLS = 64, GRID_ROWS = 48;                 // reference include/Frame.h:47,52
+
+__device__ __forceinline__ int hamming256(const uint32_t* a, const uint4 b0, const uint4 b1) {
+  int d = __popc(a[0] ^ b0.x);
+  d += __popc(a[1] ^ b0.y);
+  d += __popc(a[2] ^ b0.z);
+  d += __popc(a[3] ^ b0.w);
+  d += __popc(a[4] ^ b1.x);
+  d += __popc(a[5] ^ b1.y);
+  d += __popc(a[6] ^ b1.z);
+  d += __popc(a[7] ^ b1.w);
+  return d;
+}
+
+// ---------------------------------------------------------------------------
+// DescriptorDistance for n pairs (reference src/ORBmatcher.cc:1991-2011)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hamming_pairs_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                            int n, int* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint4 a0 = a[2 * i], a1 = a[2 * i + 1];
+  const uint32_t q[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  out[i] = hamming256(q, b[2 * i], b[2 * i + 1]);
+}
+
+// ---------------------------------------------------------------------------
+// Brute-force kNN-2.  A thread owns KQ queries in registers; database rows are
+// staged in LDS in tiles and read back as wave-uniform (broadcast) 16-byte words.
+// Per pair: 8 xor + 8 accumulating popcounts + 3 for the running two smallest
+// keys, where key = distance << 22 | row (so the first minimum wins ties, as in
+// the reference's sequential scans with a strict '<').
+// ---------------------------------------------------------------------------
+constexpr int KNN_THREADS = 256;
+constexpr int KNN_KQ = 4;
+constexpr int KNN_TILE = 512;        // database rows per LDS tile
+constexpr int KNN_ROWBITS = 22;      // rows per chunk: keys hold a chunk-local row index
+constexpr int KNN_CHUNK = 1 << KNN_ROWBITS;
+
+__global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restrict__ q, int nq,
+                                                           const uint4* __restrict__ db, int ndb, int index_base,
+                                                           float ratio, int* __restrict__ out_best,
+                                                           int* __restrict__ out_second, int* __restrict__ out_idx,
+                                                           uint8_t* __restrict__ out_accept) {
+  __shared__ uint4 s_db[2 * KNN_TILE];
+  const int tid = threadIdx.x;
+  const int q0 = (blockIdx.x * KNN_THREADS + tid) * KNN_KQ;
+  uint32_t qr[KNN_KQ][8];
+#pragma unroll
+  for (int k = 0; k < KNN_KQ; k++) {
+    const int qi = min(q0 + k, nq - 1);
+    const uint4 a0 = q[2 * qi], a1 = q[2 * qi + 1];
+    qr[k][0] = a0.x; qr[k][1] = a0.y; qr[k][2] = a0.z; qr[k][3] = a0.w;
+    qr[k][4] = a1.x; qr[k][5] = a1.y; qr[k][6] = a1.z; qr[k][7] = a1.w;
+  }
+  int bd[KNN_KQ], sd[KNN_KQ], bi[KNN_KQ];
+#pragma unroll
+  for (int k = 0; k < KNN_KQ; k++) { bd[k] = 256; sd[k] = 256; bi[k] = -1; }
+
+  for (int cbase = 0; cbase < ndb; cbase += KNN_CHUNK) {
+    const int cn = min(KNN_CHUNK, ndb - cbase);
+    uint32_t k1[KNN_KQ], k2[KNN_KQ];
+#pragma unroll
+    for (int k = 0; k < KNN_KQ; k++) { k1[k] = 0xFFFFFFFFu; k2[k] = 0xFFFFFFFFu; }
+    for (int t0 = 0; t0 < cn; t0 += KNN_TILE) {
+      const int tn = min(KNN_TILE, cn - t0);
+      __syncthreads();
+      for (int i = tid; i < 2 * tn; i += KNN_THREADS) s_db[i] = db[2 * (size_t)(cbase + t0) + i];
+      __syncthreads();
+#pragma unroll 4
+      for (int j = 0; j < tn; j++) {
+        const uint4 b0 = s_db[2 * j], b1 = s_db[2 * j + 1];
+        const uint32_t row = (uint32_t)(t0 + j);
+#pragma unroll
+        for (int k = 0; k < KNN_KQ; k++) {
+          const uint32_t d = (uint32_t)hamming256(qr[k], b0, b1);
+          const uint32_t key = (d << KNN_ROWBITS) | row;
+          k2[k] = min(k2[k], max(k1[k], key));
+          k1[k] = min(k1[k], key);
+        }
+      }
+    }
+    // fold the chunk into the running (best, second, index): an earlier chunk keeps ties
+#pragma unroll
+    for (int k = 0; k < KNN_KQ; k++) {
+      const int cb = k1[k] == 0xFFFFFFFFu ? 256 : (int)(k1[k] >> KNN_ROWBITS);
+      const int cs = k2[k] == 0xFFFFFFFFu ? 256 : (int)(k2[k] >> KNN_ROWBITS);
+      const int ci = (int)(k1[k] & (KNN_CHUNK - 1)) + cbase;
+      if (cb < bd[k]) { sd[k] = min(bd[k], cs); bd[k] = cb; bi[k] = ci; }
+      else sd[k] = min(sd[k], cb);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KNN_KQ; k++) {
+    const int qi = q0 + k;
+    if (qi < nq) {
+      out_best[qi] = bd[k];
+      out_second[qi] = sd[k];
+      out_idx[qi] = bi[k] < 0 ? -1 : bi[k] + index_base;
+      if (out_accept) out_accept[qi] = (uint8_t)(bi[k] >= 0 && (float)bd[k] < __fmul_rn(ratio, (float)sd[k]));
+    }
+  }
+}
+
+// Merge of per-shard results, shards in ascending database order: equals one scan of
+// the concatenated database (earlier shard keeps ties).
+__global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, const int* __restrict__ best,
+                                                         const int* __restrict__ second, const int* __restrict__ idx,
+                                                         float ratio, int* __restrict__ ob, int* __restrict__ os,
+                                                         int* __restrict__ oi, uint8_t* __restrict__ oa) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  int bd = 256, sd = 256, bi = -1;
+  for (int s = 0; s < nshards; s++) {
+    const int cb = best[(size_t)s * nq + i], cs = second[(size_t)s * nq + i], ci = idx[(size_t)s * nq + i];
+    if (ci >= 0 && cb < bd) { sd = min(bd, cs); bd = cb; bi = ci; }
+    else if (ci >= 0) sd = min(sd, cb);
+  }
+  ob[i] = bd; os[i] = sd; oi[i] = bi;
+  if (oa) oa[i] = (uint8_t)(bi >= 0 && (float)bd < __fmul_rn(ratio, (float)sd));
+}
+
+// ---------------------------------------------------------------------------
+// Greedy matchers
+// ---------------------------------------------------------------------------
+constexpr int MK = 4;  // ranked candidates kept per query
+constexpr int M_THREADS = 256;
+enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2 };
+
+struct MatchArgs {
+  int max_q, max_t, nlevels, check_ori;
+  const int* n_q; const int* n_t;
+  // train side (current frame / frame F / keyframe 2)
+  const float* t_x; const float* t_y; const int* t_oct; const float* t_angle;
+  const uint8_t* t_desc; const int* t_obs;       // obs: -1 = no map point (TRIANG: 0 / 1 = has map point)
+  // query side
+  const int* q_obs; const float* q_xw; const uint8_t* q_desc; const int* q_oct; const float* q_angle;
+  const float* q_x; const float* q_y; const float* q_viewcos; const uint8_t* q_track;
+  const int* q_idx1; const int* q_b0; const int* q_b1; const int* items2;  // TRIANG buckets
+  const float* tcw;
+  float fx, fy, cx, cy;
+  OrbFrameBounds b;
+  float sf[kMaxLevels];
+  float sigma2[kMaxLevels];
+  float f12[9];
+  float ex, ey, th, nnratio;
+  // scratch, per pair slices of max_q
+  uint2* lists; int* q_ntot; float4* q_geo; int* q_slot; int* q_bin;
+  // outputs
+  int* out_match; int* n_matches;
+};
+
+struct Cand { uint32_t key[MK]; uint32_t idx[MK]; int ntot; };
+
+__device__ __forceinline__ void cand_init(Cand& c) {
+#pragma unroll
+  for (int k = 0; k < MK; k++) { c.key[k] = 0xFFFFFFFFu; c.idx[k] = 0; }
+  c.ntot = 0;
+}
+__device__ __forceinline__ void cand_insert(Cand& c, uint32_t key, uint32_t idx) {
+  c.ntot++;
+  if (key >= c.key[MK - 1]) return;
+  c.key[MK - 1] = key; c.idx[MK - 1] = idx;
+#pragma unroll
+  for (int k = MK - 1; k > 0; k--) {
+    if (c.key[k] < c.key[k - 1]) {
+      const uint32_t tk = c.key[k]; c.key[k] = c.key[k - 1]; c.key[k - 1] = tk;
+      const uint32_t ti = c.idx[k]; c.idx[k] = c.idx[k - 1]; c.idx[k - 1] = ti;
+    }
+  }
+}
+
+struct MatchShared {
+  int* start;            // GRID_COLS*GRID_ROWS + 1
+  unsigned short* items; // max_t
+  float* kx; float* ky;  // max_t
+  unsigned char* koct;   // max_t
+  unsigned char* occ;    // max_t: train keypoint can no longer be taken
+};
+
+// Frame::GetFeaturesInArea (reference src/Frame.cc:371-449) fused with the best /
+// second scan of the caller.  Visits candidates in the reference's order
+// (grid column, grid row, insertion order) and ranks them by (distance, visit order).
+template <int MODE>
+__device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, int nt, const float4 geo,
+                           const uint32_t* qd, int bucket0, int bucket1, float qx, float qy, Cand& c) {
+  cand_init(c);
+  const uint4* tdesc = reinterpret_cast<const uint4*>(A.t_desc) + 2 * (size_t)pair * A.max_t;
+  if constexpr (MODE != MODE_TRIANG) {
+    const float x = geo.x, y = geo.y, r = geo.z;
+    const int lv = __float_as_int(geo.w);
+    const int minLevel = (lv & 0xFFFF) - 1024, maxLevel = (lv >> 16) - 1024;
+    const float invW = (float)GRID_COLS / (A.b.max_x - A.b.min_x);
+    const float invH = (float)GRID_ROWS / (A.b.max_y - A.b.min_y);
+    const int nMinCellX = max(0, (int)floorf((x - A.b.min_x - r) * invW));
+    if (nMinCellX >= GRID_COLS) return;
+    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - A.b.min_x + r) * invW));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = max(0, (int)floorf((y - A.b.min_y - r) * invH));
+    if (nMinCellY >= GRID_ROWS) return;
+    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - A.b.min_y + r) * invH));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int pos = 0;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+        const int cell = ix * GRID_ROWS + iy;
+        for (int p = S.start[cell]; p < S.start[cell + 1]; p++) {
+          const int j = S.items[p];
+          if (bCheckLevels) {
+            if ((int)S.koct[j] < minLevel) continue;
+            if (maxLevel >= 0 && (int)S.koct[j] > maxLevel) continue;
+          }
+          if (!(fabsf(S.kx[j] - x) < r && fabsf(S.ky[j] - y) < r)) continue;
+          const int mypos = pos++;
+          if (S.occ[j]) continue;
+          const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+          cand_insert(c, ((uint32_t)d << 20) | (uint32_t)mypos, (uint32_t)j);
+        }
+      }
+    (void)nt;
+  } else {
+    // candidates: keyframe-2 features of the same vocabulary node, in order; the
+    // reference keeps the LAST one among equal distances ('dist > bestDist' skips)
+    int pos = 0;
+    for (int p = bucket0; p < bucket1; p++, pos++) {
+      const int j = A.items2[p];
+      if (S.occ[j]) continue;
+      const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+      if (d > TH_LOW) continue;
+      const float x2 = S.kx[j], y2 = S.ky[j];
+      const float distex = A.ex - x2, distey = A.ey - y2;
+      if (distex * distex + distey * distey < 100 * A.sf[S.koct[j]]) continue;
+      // CheckDistEpipolarLine, reference src/ORBmatcher.cc:180-207
+      const float a = qx * A.f12[0] + qy * A.f12[3] + A.f12[6];
+      const float b = qx * A.f12[1] + qy * A.f12[4] + A.f12[7];
+      const float cc = qx * A.f12[2] + qy * A.f12[5] + A.f12[8];
+      const float num = a * x2 + b * y2 + cc;
+      const float den = a * a + b * b;
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (!((double)dsqr < 3.84 * (double)A.sigma2[S.koct[j]])) continue;
+      cand_insert(c, ((uint32_t)d << 20) | (uint32_t)(0xFFFFF - pos), (uint32_t)j);
+    }
+    (void)nt; (void)geo;
+  }
+}
+
+__device__ __forceinline__ int rot_bin(float rot) {
+  const float factor = HISTO_LENGTH / 360.0f;
+  if (rot < 0.0f) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_hist[HISTO_LENGTH];
+  __shared__ int s_nm, s_keep[3];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int nq = min(A.n_q[pair], A.max_q), nt = min(A.n_t[pair], A.max_t);
+  MatchShared S;
+  {
+    unsigned char* p = smem;
+    S.start = reinterpret_cast<int*>(p); p += sizeof(int) * (GRID_COLS * GRID_ROWS + 4);
+    S.kx = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
+    S.ky = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
+    S.items = reinterpret_cast<unsigned short*>(p); p += sizeof(unsigned short) * ((A.max_t + 1) & ~1);
+    S.koct = p; p += (A.max_t + 3) & ~3;
+    S.occ = p;
+  }
+  const size_t tbase = (size_t)pair * A.max_t, qbase = (size_t)pair * A.max_q;
+  int* out_match = A.out_match + (MODE == MODE_TRIANG ? qbase : tbase);
+
+  // ---- phase 0: train keypoints to LDS; 64x48 grid as CSR in insertion order
+  // (Frame::AssignFeaturesToGrid / PosInGrid, reference src/Frame.cc:190-213, 461-477)
+  for (int j = tid; j < nt; j += M_THREADS) {
+    S.kx[j] = A.t_x[tbase + j]; S.ky[j] = A.t_y[tbase + j];
+    S.koct[j] = (unsigned char)A.t_oct[tbase + j];
+    S.occ[j] = (unsigned char)(A.t_obs[tbase + j] > 0);
+    if (MODE != MODE_TRIANG) out_match[j] = -1;
+  }
+  if (MODE == MODE_TRIANG)
+    for (int i = tid; i < A.max_q; i += M_THREADS) out_match[i] = -1;
+  if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+  if (tid == 0) s_nm = 0;
+  if constexpr (MODE != MODE_TRIANG) {
+    constexpr int NC = GRID_COLS * GRID_ROWS;
+    // counts go to start[cell + 2]; after the inclusive scan start[cell + 1] is the
+    // cell's first slot, and the fill's atomic increments turn it into the cell's end,
+    // which leaves start[] as an ordinary CSR offset array
+    for (int c = tid; c < NC + 2; c += M_THREADS) S.start[c] = 0;
+    __syncthreads();
+    const float invW = (float)GRID_COLS / (A.b.max_x - A.b.min_x);
+    const float invH = (float)GRID_ROWS / (A.b.max_y - A.b.min_y);
+    for (int j = tid; j < nt; j += M_THREADS) {
+      const int px = (int)roundf((S.kx[j] - A.b.min_x) * invW), py = (int)roundf((S.ky[j] - A.b.min_y) * invH);
+      if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) atomicAdd(&S.start[px * GRID_ROWS + py + 2], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {  // inclusive scan of the 3072 counts, 48 per lane
+      int sum = 0;
+      for (int k = 0; k < GRID_ROWS; k++) sum += S.start[tid * GRID_ROWS + k + 2];
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (tid >= o) incl += v; }
+      int run = incl - sum;
+      for (int k = 0; k < GRID_ROWS; k++) { run += S.start[tid * GRID_ROWS + k + 2]; S.start[tid * GRID_ROWS + k + 2] = run; }
+    }
+    __syncthreads();
+    for (int j = tid; j < nt; j += M_THREADS) {
+      const int px = (int)roundf((S.kx[j] - A.b.min_x) * invW), py = (int)roundf((S.ky[j] - A.b.min_y) * invH);
+      if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS)
+        S.items[atomicAdd(&S.start[px * GRID_ROWS + py + 1], 1)] = (unsigned short)j;
+    }
+    __syncthreads();
+    // insertion order inside a cell is ascending keypoint index
+    for (int c = tid; c < NC; c += M_THREADS) {
+      const int b = S.start[c], e = S.start[c + 1];
+      for (int i = b + 1; i < e; i++) {
+        const unsigned short v = S.items[i];
+        int k = i - 1;
+        while (k >= b && S.items[k] > v) { S.items[k + 1] = S.items[k]; k--; }
+        S.items[k + 1] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase A: every query ranks its candidates against the initial occupancy
+  for (int i = tid; i < nq; i += M_THREADS) {
+    float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool valid = true;
+    int b0 = 0, b1 = 0;
+    float qx = 0.f, qy = 0.f;
+    const uint8_t* qdesc_ptr;
+    if constexpr (MODE == MODE_FRAMES) {
+      // projection, reference src/ORBmatcher.cc:1669-1712
+      valid = A.q_obs[qbase + i] >= 0;
+      const float* T = A.tcw + 16 * (size_t)pair;
+      const float* X = A.q_xw + 3 * (qbase + i);
+      const float xc = (T[0] * X[0] + T[1] * X[1] + T[2] * X[2]) + T[3];
+      const float yc = (T[4] * X[0] + T[5] * X[1] + T[6] * X[2]) + T[7];
+      const float zc = (T[8] * X[0] + T[9] * X[1] + T[10] * X[2]) + T[11];
+      const float invzc = (float)(1.0 / (double)zc);
+      if (invzc < 0) valid = false;
+      const float u = A.fx * xc * invzc + A.cx, v = A.fy * yc * invzc + A.cy;
+      if (u < A.b.min_x || u > A.b.max_x || v < A.b.min_y || v > A.b.max_y || isnan(u) || isnan(v)) valid = false;
+      int oct = A.q_oct[qbase + i];
+      oct = min(max(oct, 0), A.nlevels - 1);
+      geo.x = u; geo.y = v; geo.z = A.th * A.sf[oct];
+      geo.w = __int_as_float(((oct - 1 + 1024) & 0xFFFF) | ((oct + 1 + 1024) << 16));
+      qdesc_ptr = A.q_desc + 32 * (qbase + i);
+    } else if constexpr (MODE == MODE_MAPPOINTS) {
+      // window, reference src/ORBmatcher.cc:75-96
+      valid = A.q_track[qbase + i] != 0;
+      int lvl = A.q_oct[qbase + i];
+      lvl = min(max(lvl, 0), A.nlevels - 1);
+      float r = (double)A.q_viewcos[qbase + i] > 0.998 ? 2.5f : 4.0f;
+      if ((double)A.th != 1.0) r *= A.th;
+      geo.x = A.q_x[qbase + i]; geo.y = A.q_y[qbase + i]; geo.z = r * A.sf[lvl];
+      geo.w = __int_as_float(((lvl - 1 + 1024) & 0xFFFF) | ((lvl + 1024) << 16));
+      qdesc_ptr = A.q_desc + 32 * (qbase + i);
+    } else {
+      const int idx1 = A.q_idx1[qbase + i];
+      b0 = A.q_b0[qbase + i]; b1 = A.q_b1[qbase + i];
+      valid = A.q_obs[(size_t)pair * A.max_q + idx1] <= 0;  // no map point yet
+      qx = A.q_x[qbase + idx1]; qy = A.q_y[qbase + idx1];
+      qdesc_ptr = A.q_desc + 32 * (qbase + idx1);
+    }
+    Cand c;
+    cand_init(c);
+    if (valid) {
+      const uint4 d0 = reinterpret_cast<const uint4*>(qdesc_ptr)[0], d1 = reinterpret_cast<const uint4*>(qdesc_ptr)[1];
+      const uint32_t qd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      scan_query<MODE>(A, S, pair, nt, geo, qd, b0, b1, qx, qy, c);
+    }
+    A.q_geo[qbase + i] = geo;
+    A.q_ntot[qbase + i] = valid ? c.ntot : -1;
+#pragma unroll
+    for (int k = 0; k < MK; k++) A.lists[(qbase + i) * MK + k] = make_uint2(c.key[k], c.idx[k]);
+    A.q_slot[qbase + i] = -1;
+    A.q_bin[qbase + i] = -1;
+  }
+  __syncthreads();
+
+  // ---- phase B: replay the reference's query order, 64 queries per step
+  if (tid < 64) {
+    const int lane = tid;
+    for (int base = 0; base < nq; base += 64) {
+      const int i = base + lane;
+      const bool active = i < nq && A.q_ntot[qbase + min(i, nq - 1)] > 0;
+      Cand c;
+      cand_init(c);
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < MK; k++) { const uint2 e = A.lists[(qbase + i) * MK + k]; c.key[k] = e.x; c.idx[k] = e.y; }
+        c.ntot = A.q_ntot[qbase + i];
+      }
+      bool resolved = !active;
+      while (true) {
+        // first and second candidate that are still free
+        int s1 = -1, s2 = -1, d1 = 256, d2 = 256;
+        if (!resolved) {
+          bool need_rescan = false;
+          int found = 0;
+#pragma unroll
+          for (int k = 0; k < MK; k++) {
+            if (c.key[k] != 0xFFFFFFFFu && !S.occ[c.idx[k]]) {
+              if (found == 0) { s1 = (int)c.idx[k]; d1 = (int)(c.key[k] >> 20); }
+              else if (found == 1) { s2 = (int)c.idx[k]; d2 = (int)(c.key[k] >> 20); }
+              found++;
+            }
+          }
+          const int want = MODE == MODE_MAPPOINTS ? 2 : 1;
+          // c.ntot > MK: candidates beyond the kept ones exist, so the list is not exhaustive
+          if (found < want && c.ntot > MK) need_rescan = true;
+          if (need_rescan) {
+            // the kept list ran out: scan again against the current occupancy
+            const float4 geo = A.q_geo[qbase + i];
+            const uint8_t* qp;
+            int b0 = 0, b1 = 0; float qx = 0.f, qy = 0.f;
+            if constexpr (MODE == MODE_TRIANG) {
+              const int idx1 = A.q_idx1[qbase + i];
+              b0 = A.q_b0[qbase + i]; b1 = A.q_b1[qbase + i];
+              qx = A.q_x[qbase + idx1]; qy = A.q_y[qbase + idx1];
+              qp = A.q_desc + 32 * (qbase + idx1);
+            } else {
+              qp = A.q_desc + 32 * (qbase + i);
+            }
+            const uint4 e0 = reinterpret_cast<const uint4*>(qp)[0], e1 = reinterpret_cast<const uint4*>(qp)[1];
+            const uint32_t qd[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+            scan_query<MODE>(A, S, pair, nt, geo, qd, b0, b1, qx, qy, c);
+            s1 = s2 = -1; d1 = d2 = 256;
+            if (c.key[0] != 0xFFFFFFFFu) { s1 = (int)c.idx[0]; d1 = (int)(c.key[0] >> 20); }
+            if (c.key[1] != 0xFFFFFFFFu) { s2 = (int)c.idx[1]; d2 = (int)(c.key[1] >> 20); }
+          }
+        }
+        // decision of this query if nothing before it in this step interferes
+        bool accept = false, occupy = false;
+        if (!resolved && s1 >= 0) {
+          if constexpr (MODE == MODE_FRAMES) {
+            accept = d1 <= TH_HIGH;
+            occupy = accept && A.q_obs[qbase + i] > 0;
+          } else if constexpr (MODE == MODE_MAPPOINTS) {
+            accept = d1 <= TH_HIGH;
+            if (accept) {
+              const int l1 = S.koct[s1], l2 = s2 >= 0 ? (int)S.koct[s2] : -1;
+              if (l1 == l2 && (float)d1 > A.nnratio * (float)d2) accept = false;
+            }
+            occupy = accept && A.q_obs[qbase + i] > 0;
+          } else {
+            accept = true;  // thresholds were applied during the scan
+            occupy = true;
+          }
+        }
+        // does an earlier unresolved query of this step take a slot this one looks at?
+        bool conflict = false;
+        const unsigned long long pending = __ballot(!resolved);
+        if (pending == 0) break;
+        for (int o = 0; o < 64; o++) {
+          if (!((pending >> o) & 1ull)) continue;  // uniform
+          const int os = __shfl(occupy ? s1 : -1, o);
+          if (o < lane && !resolved && os >= 0 && (os == s1 || (MODE == MODE_MAPPOINTS && os == s2))) conflict = true;
+        }
+        const unsigned long long cm = __ballot(conflict);
+        const int first_conf = cm ? (__ffsll((long long)cm) - 1) : 64;
+        if (!resolved && lane < first_conf) {
+          resolved = true;
+          if (accept) {
+            if (occupy) S.occ[s1] = 1;
+            atomicAdd(&s_nm, 1);
+            if constexpr (MODE == MODE_TRIANG) {
+              const int idx1 = A.q_idx1[qbase + i];
+              out_match[idx1] = s1;
+              A.q_slot[qbase + i] = idx1;
+              if (A.check_ori) A.q_bin[qbase + i] = rot_bin(A.q_angle[qbase + idx1] - A.t_angle[tbase + s1]);
+            } else {
+              atomicMax(&out_match[s1], i);  // a later query overwrites an earlier one
+              A.q_slot[qbase + i] = s1;
+              if (MODE == MODE_FRAMES && A.check_ori)
+                A.q_bin[qbase + i] = rot_bin(A.q_angle[qbase + i] - A.t_angle[tbase + s1]);
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase C: rotation consistency (reference src/ORBmatcher.cc:1765-1785, 1014-1034,
+  // ComputeThreeMaxima :1943-1985)
+  if (A.check_ori && MODE != MODE_MAPPOINTS) {
+    for (int i = tid; i < nq; i += M_THREADS) {
+      const int b = A.q_bin[qbase + i];
+      if (b >= 0) atomicAdd(&s_hist[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+      for (int i = 0; i < HISTO_LENGTH; i++) {
+        const int s = s_hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+      }
+      if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+      else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+      s_keep[0] = ind1; s_keep[1] = ind2; s_keep[2] = ind3;
+    }
+    __syncthreads();
+    for (int i = tid; i < nq; i += M_THREADS) {
+      const int b = A.q_bin[qbase + i];
+      if (b >= 0 && b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) {
+        out_match[A.q_slot[qbase + i]] = MODE == MODE_TRIANG ? -1 : -2;
+        atomicSub(&s_nm, 1);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) A.n_matches[pair] = s_nm;
+}
+
+size_t match_lds_bytes(int max_t) {
+  return sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + 2 * sizeof(float) * (size_t)max_t +
+         sizeof(unsigned short) * (size_t)((max_t + 1) & ~1) + (size_t)((max_t + 3) & ~3) + (size_t)max_t + 16;
+}
+
+// ---- host helpers -------------------------------------------------------------
+struct DevBuf {
+  std::vector<void*> ptrs;
+  ~DevBuf() { for (void* p : ptrs) hipFree(p); }
+  template <typename T, typename U>
+  int up(const T* host, size_t n, U** out) {
+    static_assert(sizeof(T) == sizeof(U), "element size mismatch");
+    *out = nullptr;
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    ptrs.push_back(d);
+    if (host && n) {
+      e = hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpy H2D");
+    }
+    *out = reinterpret_cast<U*>(d);
+    return ORBHIP_OK;
+  }
+};
+
+struct DevSel {
+  int prev = -1;
+  explicit DevSel(int dev) { hipGetDevice(&prev); if (prev != dev) hipSetDevice(dev); else prev = -1; }
+  ~DevSel() { if (prev >= 0) hipSetDevice(prev); }
+};
+
+#define UP(buf, host, n, out)                         \
+  do {                                                \
+    int rc__ = (buf).up((host), (size_t)(n), &(out)); \
+    if (rc__ != ORBHIP_OK) return rc__;               \
+  } while (0)
+
+template <int MODE>
+int run_match(MatchArgs& A, int n_pairs, DevBuf& buf) {
+  const size_t nq = (size_t)n_pairs * A.max_q;
+  UP(buf, (const uint2*)nullptr, nq * MK, A.lists);
+  UP(buf, (const int*)nullptr, nq, A.q_ntot);
+  UP(buf, (const float4*)nullptr, nq, A.q_geo);
+  UP(buf, (const int*)nullptr, nq, A.q_slot);
+  UP(buf, (const int*)nullptr, nq, A.q_bin);
+  const size_t lds = match_lds_bytes(A.max_t);
+  if (lds > 150 * 1024) { set_error("too many train keypoints for the LDS-resident grid (limit about 11000)"); return ORBHIP_ERR_UNSUPPORTED; }
+  ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_kernel<MODE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(match_kernel<MODE>, dim3(n_pairs), dim3(M_THREADS), lds, 0, A);
+  ORB_HIP_CHECK(hipGetLastError());
+  ORB_HIP_CHECK(hipDeviceSynchronize());
+  return ORBHIP_OK;
+}
+
+}  // namespace orbhip
+
+using namespace orbhip;
+
+extern "C" {
+
+int orb_hamming_distance_pairs(int device_id, const uint8_t* a, const uint8_t* b, int n, int* out) {
+  if (n <= 0) return ORBHIP_OK;
+  if (!a || !b || !out) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  DevBuf buf;
+  uint8_t *da, *db; int* dout;
+  UP(buf, a, (size_t)n * 32, da);
+  UP(buf, b, (size_t)n * 32, db);
+  UP(buf, (const int*)nullptr, n, dout);
+  hipLaunchKernelGGL(hamming_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const uint4*)da, (const uint4*)db, n, dout);
+  ORB_HIP_CHECK(hipGetLastError());
+  ORB_HIP_CHECK(hipMemcpy(out, dout, sizeof(int) * n, hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_knn2_device(int device_id, const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db, int db_index_base,
+                    float ratio, int* d_best, int* d_second, int* d_idx, uint8_t* d_accept, void* stream) {
+  if (n_q <= 0) return ORBHIP_OK;
+  if (!d_q || !d_best || !d_second || !d_idx || (n_db > 0 && !d_db) || n_db < 0) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if (((uintptr_t)d_q | (uintptr_t)d_db) & 15) { set_error("descriptor arrays must be 16-byte aligned"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  const int per_block = KNN_THREADS * KNN_KQ;
+  hipLaunchKernelGGL(knn2_kernel, dim3((n_q + per_block - 1) / per_block), dim3(KNN_THREADS), 0, (hipStream_t)stream,
+                     (const uint4*)d_q, n_q, (const uint4*)d_db, n_db, db_index_base, ratio, d_best, d_second, d_idx,
+                     d_accept);
+  ORB_HIP_CHECK(hipGetLastError());
+  return ORBHIP_OK;
+}
+
+int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_best, const int* d_second,
+                          const int* d_idx, float ratio, int* d_out_best, int* d_out_second, int* d_out_idx,
+                          uint8_t* d_out_accept, void* stream) {
+  if (n_q <= 0) return ORBHIP_OK;
+  if (n_shards < 1 || !d_best || !d_second || !d_idx || !d_out_best || !d_out_second || !d_out_idx) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  hipLaunchKernelGGL(knn2_merge_kernel, dim3((n_q + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_shards, n_q,
+                     d_best, d_second, d_idx, ratio, d_out_best, d_out_second, d_out_idx, d_out_accept);
+  ORB_HIP_CHECK(hipGetLastError());
+  return ORBHIP_OK;
+}
+
+int orb_knn2_bruteforce(int device_id, const uint8_t* q, int n_q, const uint8_t* db, int n_db, float ratio, int* best,
+                        int* second, int* idx, uint8_t* accept) {
+  if (n_q <= 0) return ORBHIP_OK;
+  if (!q || !best || !second || !idx || (n_db > 0 && !db)) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  DevBuf buf;
+  uint8_t *dq, *ddb, *dacc; int *db_, *ds_, *di_;
+  UP(buf, q, (size_t)n_q * 32, dq);
+  UP(buf, db, (size_t)n_db * 32, ddb);
+  UP(buf, (const int*)nullptr, n_q, db_);
+  UP(buf, (const int*)nullptr, n_q, ds_);
+  UP(buf, (const int*)nullptr, n_q, di_);
+  UP(buf, (const uint8_t*)nullptr, n_q, dacc);
+  int rc = orb_knn2_device(device_id, dq, n_q, ddb, n_db, 0, ratio, db_, ds_, di_, dacc, nullptr);
+  if (rc != ORBHIP_OK) return rc;
+  ORB_HIP_CHECK(hipDeviceSynchronize());
+  ORB_HIP_CHECK(hipMemcpy(best, db_, sizeof(int) * n_q, hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpy(second, ds_, sizeof(int) * n_q, hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpy(idx, di_, sizeof(int) * n_q, hipMemcpyDeviceToHost));
+  if (accept) ORB_HIP_CHECK(hipMemcpy(accept, dacc, n_q, hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_search_by_projection_frames(int device_id, int n_pairs, int max_last, int max_cur, const float* tcw, float fx,
+                                    float fy, float cx, float cy, OrbFrameBounds bounds, const float* scale_factors,
+                                    int nlevels, const int* n_last, const int* last_mp_obs, const float* last_xw,
+                                    const uint8_t* last_mp_desc, const int* last_octave, const float* last_angle,
+                                    const int* n_cur, const float* cur_x, const float* cur_y, const int* cur_octave,
+                                    const float* cur_angle, const uint8_t* cur_desc, const int* cur_obs, float th,
+                                    int check_orientation, int* cur_match, int* n_matches) {
+  if (n_pairs <= 0) return ORBHIP_OK;
+  if (max_last <= 0 || max_cur <= 0 || max_cur > 65535 || nlevels < 1 || nlevels > kMaxLevels) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
+  if (!tcw || !scale_factors || !n_last || !last_mp_obs || !last_xw || !last_mp_desc || !last_octave || !last_angle ||
+      !n_cur || !cur_x || !cur_y || !cur_octave || !cur_angle || !cur_desc || !cur_obs || !cur_match || !n_matches) {
+    set_error("null argument"); return ORBHIP_ERR_ARG;
+  }
+  DevSel g(device_id);
+  DevBuf buf;
+  MatchArgs A{};
+  A.max_q = max_last; A.max_t = max_cur; A.nlevels = nlevels; A.check_ori = check_orientation;
+  A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.b = bounds; A.th = th;
+  for (int i = 0; i < nlevels; i++) A.sf[i] = scale_factors[i];
+  const size_t nq = (size_t)n_pairs * max_last, nt = (size_t)n_pairs * max_cur;
+  UP(buf, n_last, n_pairs, A.n_q); UP(buf, n_cur, n_pairs, A.n_t);
+  UP(buf, tcw, (size_t)n_pairs * 16, A.tcw);
+  UP(buf, last_mp_obs, nq, A.q_obs); UP(buf, last_xw, nq * 3, A.q_xw); UP(buf, last_mp_desc, nq * 32, A.q_desc);
+  UP(buf, last_octave, nq, A.q_oct); UP(buf, last_angle, nq, A.q_angle);
+  UP(buf, cur_x, nt, A.t_x); UP(buf, cur_y, nt, A.t_y); UP(buf, cur_octave, nt, A.t_oct);
+  UP(buf, cur_angle, nt, A.t_angle); UP(buf, cur_desc, nt * 32, A.t_desc); UP(buf, cur_obs, nt, A.t_obs);
+  UP(buf, (const int*)nullptr, nt, A.out_match); UP(buf, (const int*)nullptr, n_pairs, A.n_matches);
+  int rc = run_match<MODE_FRAMES>(A, n_pairs, buf);
+  if (rc != ORBHIP_OK) return rc;
+  ORB_HIP_CHECK(hipMemcpy(cur_match, A.out_match, sizeof(int) * nt, hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int) * n_pairs, hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_search_by_projection_mappoints(int device_id, OrbFrameBounds bounds, const float* scale_factors, int nlevels,
+                                       int n_f, const float* f_x, const float* f_y, const int* f_octave,
+                                       const uint8_t* f_desc, const int* f_obs, int n_mp, const uint8_t* mp_track,
+                                       const int* mp_level, const float* mp_viewcos, const float* mp_projx,
+                                       const float* mp_projy, const uint8_t* mp_desc, const int* mp_obs, float th,
+                                       float nnratio, int* f_match, int* n_matches) {
+  if (!n_matches) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  *n_matches = 0;
+  if (n_f <= 0) return ORBHIP_OK;
+  if (n_f > 65535 || nlevels < 1 || nlevels > kMaxLevels) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
+  if (!f_match || !scale_factors || !f_x || !f_y || !f_octave || !f_desc || !f_obs) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if (n_mp <= 0) { for (int i = 0; i < n_f; i++) f_match[i] = -1; return ORBHIP_OK; }
+  if (!mp_track || !mp_level || !mp_viewcos || !mp_projx || !mp_projy || !mp_desc || !mp_obs) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  DevBuf buf;
+  MatchArgs A{};
+  A.max_q = n_mp; A.max_t = n_f; A.nlevels = nlevels; A.check_ori = 0;
+  A.b = bounds; A.th = th; A.nnratio = nnratio;
+  for (int i = 0; i < nlevels; i++) A.sf[i] = scale_factors[i];
+  UP(buf, &n_mp, 1, A.n_q); UP(buf, &n_f, 1, A.n_t);
+  UP(buf, mp_track, n_mp, A.q_track); UP(buf, mp_level, n_mp, A.q_oct); UP(buf, mp_viewcos, n_mp, A.q_viewcos);
+  UP(buf, mp_projx, n_mp, A.q_x); UP(buf, mp_projy, n_mp, A.q_y); UP(buf, mp_desc, (size_t)n_mp * 32, A.q_desc);
+  UP(buf, mp_obs, n_mp, A.q_obs);
+  UP(buf, f_x, n_f, A.t_x); UP(buf, f_y, n_f, A.t_y); UP(buf, f_octave, n_f, A.t_oct);
+  UP(buf, f_desc, (size_t)n_f * 32, A.t_desc); UP(buf, f_obs, n_f, A.t_obs);
+  A.t_angle = A.t_x;
+  UP(buf, (const int*)nullptr, n_f, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
+  int rc = run_match<MODE_MAPPOINTS>(A, 1, buf);
+  if (rc != ORBHIP_OK) return rc;
+  ORB_HIP_CHECK(hipMemcpy(f_match, A.out_match, sizeof(int) * n_f, hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_search_for_triangulation(int device_id, int n1, const float* x1, const float* y1, const int* octave1,
+                                 const float* angle1, const uint8_t* desc1, const uint8_t* has_mp1, int n2,
+                                 const float* x2, const float* y2, const int* octave2, const float* angle2,
+                                 const uint8_t* desc2, const uint8_t* has_mp2, int n_nodes1, const int* node1,
+                                 const int* start1, const int* items1, int n_nodes2, const int* node2,
+                                 const int* start2, const int* items2, const float* f12, float ex, float ey,
+                                 const float* scale_factors2, const float* level_sigma2_2, int nlevels,
+                                 int check_orientation, int* matches12, int* n_matches) {
+  (void)octave1;
+  if (!n_matches) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  *n_matches = 0;
+  if (n1 <= 0) return ORBHIP_OK;
+  if (!matches12) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n2 <= 0 || n_nodes1 <= 0 || n_nodes2 <= 0) return ORBHIP_OK;
+  if (n2 > 65535 || nlevels < 1 || nlevels > kMaxLevels) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
+  if (!x1 || !y1 || !angle1 || !desc1 || !has_mp1 || !x2 || !y2 || !octave2 || !angle2 || !desc2 || !has_mp2 ||
+      !node1 || !start1 || !items1 || !node2 || !start2 || !items2 || !f12 || !scale_factors2 || !level_sigma2_2) {
+    set_error("null argument"); return ORBHIP_ERR_ARG;
+  }
+  // merge-walk of the two ordered feature vectors (reference src/ORBmatcher.cc:894-1011):
+  // the queries, in the reference's visiting order, each with its keyframe-2 bucket
+  std::vector<int> q_idx1, q_b0, q_b1;
+  for (int a = 0, b = 0; a < n_nodes1 && b < n_nodes2;) {
+    if (node1[a] == node2[b]) {
+      for (int p = start1[a]; p < start1[a + 1]; p++) {
+        const int idx1 = items1[p];
+        if (idx1 < 0 || idx1 >= n1) { set_error("feature index out of range"); return ORBHIP_ERR_ARG; }
+        q_idx1.push_back(idx1); q_b0.push_back(start2[b]); q_b1.push_back(start2[b + 1]);
+      }
+      a++; b++;
+    } else if (node1[a] < node2[b]) {
+      a = (int)(std::lower_bound(node1 + a, node1 + n_nodes1, node2[b]) - node1);
+    } else {
+      b = (int)(std::lower_bound(node2 + b, node2 + n_nodes2, node1[a]) - node2);
+    }
+  }
+  const int nq = (int)q_idx1.size();
+  if (nq == 0) return ORBHIP_OK;
+  const int nitems2 = start2[n_nodes2];
+  for (int p = 0; p < nitems2; p++)
+    if (items2[p] < 0 || items2[p] >= n2) { set_error("feature index out of range"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  DevBuf buf;
+  MatchArgs A{};
+  const int max_q = std::max(nq, n1);  // per-pair slices hold both query-indexed and idx1-indexed arrays
+  A.max_q = max_q; A.max_t = n2; A.nlevels = nlevels; A.check_ori = check_orientation;
+  A.ex = ex; A.ey = ey;
+  for (int i = 0; i < 9; i++) A.f12[i] = f12[i];
+  for (int i = 0; i < nlevels; i++) { A.sf[i] = scale_factors2[i]; A.sigma2[i] = level_sigma2_2[i]; }
+  std::vector<int> obs1(max_q, 0), obs2(n2), oct2(n2);
+  for (int i = 0; i < n1; i++) obs1[i] = has_mp1[i] ? 1 : 0;
+  for (int i = 0; i < n2; i++) { obs2[i] = has_mp2[i] ? 1 : 0; oct2[i] = std::min(std::max(octave2[i], 0), nlevels - 1); }
+  std::vector<float> qx(max_q, 0.f), qy(max_q, 0.f), qa(max_q, 0.f);
+  std::vector<uint8_t> qd((size_t)max_q * 32, 0);
+  std::copy(x1, x1 + n1, qx.begin()); std::copy(y1, y1 + n1, qy.begin()); std::copy(angle1, angle1 + n1, qa.begin());
+  std::copy(desc1, desc1 + (size_t)n1 * 32, qd.begin());
+  q_idx1.resize(max_q, 0); q_b0.resize(max_q, 0); q_b1.resize(max_q, 0);
+  UP(buf, &nq, 1, A.n_q); UP(buf, &n2, 1, A.n_t);
+  UP(buf, obs1.data(), max_q, A.q_obs); UP(buf, qx.data(), max_q, A.q_x); UP(buf, qy.data(), max_q, A.q_y);
+  UP(buf, qa.data(), max_q, A.q_angle); UP(buf, qd.data(), (size_t)max_q * 32, A.q_desc);
+  UP(buf, q_idx1.data(), max_q, A.q_idx1); UP(buf, q_b0.data(), max_q, A.q_b0); UP(buf, q_b1.data(), max_q, A.q_b1);
+  UP(buf, items2, nitems2, A.items2);
+  UP(buf, x2, n2, A.t_x); UP(buf, y2, n2, A.t_y); UP(buf, oct2.data(), n2, A.t_oct); UP(buf, angle2, n2, A.t_angle);
+  UP(buf, desc2, (size_t)n2 * 32, A.t_desc); UP(buf, obs2.data(), n2, A.t_obs);
+  UP(buf, (const int*)nullptr, max_q, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
+  int rc = run_match<MODE_TRIANG>(A, 1, buf);
+  if (rc != ORBHIP_OK) return rc;
+  std::vector<int> m(max_q);
+  ORB_HIP_CHECK(hipMemcpy(m.data(), A.out_match, sizeof(int) * max_q, hipMemcpyDeviceToHost));
+  std::copy(m.begin(), m.begin() + n1, matches12);
+  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""Minimal host-side stand-ins for the reference's Frame / KeyFrame / MapPoint: just the
+state the hot matchers read and write (reference include/Frame.h, KeyFrame.h, MapPoint.h).
+They exist so that ORBmatcher below keeps the reference's call signatures."""
+import numpy as np
+
+
+class MapPoint:
+    def __init__(self, world_pos, descriptor, observations=1):
+        self._pos = np.asarray(world_pos, np.float32).reshape(3)
+        self._desc = np.asarray(descriptor, np.uint8).reshape(32)
+        self._nobs = int(observations)
+        self._bad = False
+        # filled by Frame::isInFrustum in the reference (src/Frame.cc:343-355)
+        self.mbNeedTrackInView = False
+        self.mnTrackedScaleLevel = 0
+        self.mTrackedViewCosine = 1.0
+        self.mTrackedProjX = 0.0
+        self.mTrackedProjY = 0.0
+
+    def GetWorldPos(self):
+        return self._pos
+
+    def GetDescriptor(self):
+        return self._desc
+
+    def Observations(self):
+        return self._nobs
+
+    def isBad(self):
+        return self._bad
+
+
+class Frame:
+    """Keypoints, descriptors, pose and map-point slots of one image."""
+
+    def __init__(self, keypoints, descriptors, scale_factors, level_sigma2, K, bounds, Tcw=None):
+        """keypoints: structured array with x, y, octave, angle (undistorted = raw: the
+        reference's UndistortKeyPoints is the identity for zero distortion, src/Frame.cc:506-510);
+        K = (fx, fy, cx, cy); bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+        self.mvKeys = keypoints
+        self.mvKeysUn = keypoints
+        self.N = len(keypoints)
+        self.mDescriptors = np.ascontiguousarray(descriptors, np.uint8).reshape(self.N, 32)
+        self.mvScaleFactors = np.asarray(scale_factors, np.float32)
+        self.mvLevelSigma2 = np.asarray(level_sigma2, np.float32)
+        self.fx, self.fy, self.cx, self.cy = (float(v) for v in K)
+        self.mnMinX, self.mnMaxX, self.mnMinY, self.mnMaxY = (float(v) for v in bounds)
+        self.mTcw = np.eye(4, dtype=np.float32) if Tcw is None else np.asarray(Tcw, np.float32).reshape(4, 4)
+        self.mvpMapPoints = [None] * self.N
+
+
+class KeyFrame(Frame):
+    """Adds what SearchForTriangulation reads: the feature vector (vocabulary node ->
+    feature indices, ordered by node id) and the pose accessors."""
+
+    def __init__(self, *args, feat_vec=None, **kw):
+        super().__init__(*args, **kw)
+        self.mFeatVec = dict(sorted((feat_vec or {}).items()))
+
+    def GetMapPoint(self, idx):
+        return self.mvpMapPoints[idx]
+
+    def GetRotation(self):
+        return self.mTcw[:3, :3]
+
+    def GetTranslation(self):
+        return self.mTcw[:3, 3]
+
+    def GetCameraCenter(self):
+        R, t = self.mTcw[:3, :3], self.mTcw[:3, 3]
+        return (-(R.T.astype(np.float32) @ t)).astype(np.float32)

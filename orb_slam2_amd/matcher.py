@@ -1,0 +1,204 @@
+"""Host-side mirror of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:41-221) over
+the C ABI of liborbhip.so.  The candidate scans and Hamming distances run on the GPU; this
+layer only flattens the caller's objects into arrays and writes the matches back."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FrameBounds, check, ptr
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+def _mat3_mul_add(R, x, t):
+    """R*x + t the way OpenCV's small-matrix gemm evaluates it for CV_32F operands:
+    three-term float dot products accumulated left to right, then one float add
+    (used by the reference at src/ORBmatcher.cc:867, 1675)."""
+    R, x, t = np.asarray(R, np.float32), np.asarray(x, np.float32), np.asarray(t, np.float32)
+    out = np.empty(3, np.float32)
+    for r in range(3):
+        acc = np.float32(R[r, 0] * x[0])
+        acc = np.float32(acc + np.float32(R[r, 1] * x[1]))
+        acc = np.float32(acc + np.float32(R[r, 2] * x[2]))
+        out[r] = np.float32(acc + t[r])
+    return out
+
+
+class ORBmatcher:
+    TH_LOW = 50
+    TH_HIGH = 100
+    HISTO_LENGTH = 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self._lib = _lib.lib()
+        self.mfNNratio = float(np.float32(nnratio))
+        self.mbCheckOrientation = bool(checkOri)
+        self.device = int(device)
+
+    # ---- DescriptorDistance (reference src/ORBmatcher.cc:1991-2011) ----------------
+    @staticmethod
+    def DescriptorDistance(a, b, device=0):
+        return int(ORBmatcher.DescriptorDistances(np.asarray(a).reshape(1, 32), np.asarray(b).reshape(1, 32), device)[0])
+
+    @staticmethod
+    def DescriptorDistances(a, b, device=0):
+        a, b = _u8(a).reshape(-1, 32), _u8(b).reshape(-1, 32)
+        assert a.shape == b.shape
+        out = np.zeros(len(a), np.int32)
+        check(_lib.lib().orb_hamming_distance_pairs(int(device), ptr(a), ptr(b), len(a), ptr(out)))
+        return out
+
+    # ---- SearchByProjection(Frame&, const Frame&, th, bMono) (:1633) ----------------
+    def SearchByProjection(self, *args):
+        if len(args) >= 2 and hasattr(args[1], "mvpMapPoints"):
+            return self._search_frames(*args)
+        return self._search_mappoints(*args)
+
+    def _search_frames(self, CurrentFrame, LastFrame, th, bMono=True):
+        n, cur_match = self.search_by_projection_frames_batch([CurrentFrame], [LastFrame], th)
+        m = cur_match[0]
+        for i2 in range(CurrentFrame.N):
+            if m[i2] >= 0:
+                CurrentFrame.mvpMapPoints[i2] = LastFrame.mvpMapPoints[m[i2]]
+            elif m[i2] == -2:
+                CurrentFrame.mvpMapPoints[i2] = None
+        return int(n[0])
+
+    def search_by_projection_frames_batch(self, cur_frames, last_frames, th):
+        """Independent (Last, Cur) pairs with equal intrinsics in one launch.  Returns
+        (n_matches[pairs], cur_match[pairs][max_cur]) with the C ABI's encoding."""
+        npairs = len(cur_frames)
+        max_last = max(1, max(f.N for f in last_frames))
+        max_cur = max(1, max(f.N for f in cur_frames))
+        c0 = cur_frames[0]
+        tcw = np.zeros((npairs, 16), np.float32)
+        n_last, n_cur = np.zeros(npairs, np.int32), np.zeros(npairs, np.int32)
+        l_obs = np.full((npairs, max_last), -1, np.int32)
+        l_xw = np.zeros((npairs, max_last, 3), np.float32)
+        l_desc = np.zeros((npairs, max_last, 32), np.uint8)
+        l_oct = np.zeros((npairs, max_last), np.int32)
+        l_ang = np.zeros((npairs, max_last), np.float32)
+        c_x, c_y, c_ang = (np.zeros((npairs, max_cur), np.float32) for _ in range(3))
+        c_oct = np.zeros((npairs, max_cur), np.int32)
+        c_desc = np.zeros((npairs, max_cur, 32), np.uint8)
+        c_obs = np.full((npairs, max_cur), -1, np.int32)
+        for p, (cur, last) in enumerate(zip(cur_frames, last_frames)):
+            tcw[p] = cur.mTcw.reshape(16)
+            n_last[p], n_cur[p] = last.N, cur.N
+            for i, mp in enumerate(last.mvpMapPoints):
+                if mp is not None:
+                    l_obs[p, i] = mp.Observations()
+                    l_xw[p, i] = mp.GetWorldPos()
+                    l_desc[p, i] = mp.GetDescriptor()
+            l_oct[p, :last.N] = last.mvKeys["octave"]
+            l_ang[p, :last.N] = last.mvKeysUn["angle"]
+            c_x[p, :cur.N], c_y[p, :cur.N] = cur.mvKeysUn["x"], cur.mvKeysUn["y"]
+            c_oct[p, :cur.N], c_ang[p, :cur.N] = cur.mvKeysUn["octave"], cur.mvKeysUn["angle"]
+            c_desc[p, :cur.N] = cur.mDescriptors
+            for i2, mp in enumerate(cur.mvpMapPoints):
+                if mp is not None:
+                    c_obs[p, i2] = mp.Observations()
+        sf = _f32(c0.mvScaleFactors)
+        cur_match = np.zeros((npairs, max_cur), np.int32)
+        nm = np.zeros(npairs, np.int32)
+        b = FrameBounds(c0.mnMinX, c0.mnMaxX, c0.mnMinY, c0.mnMaxY)
+        check(self._lib.orb_search_by_projection_frames(
+            self.device, npairs, max_last, max_cur, ptr(tcw), c0.fx, c0.fy, c0.cx, c0.cy, b, ptr(sf), len(sf),
+            ptr(n_last), ptr(l_obs), ptr(l_xw), ptr(l_desc), ptr(l_oct), ptr(l_ang),
+            ptr(n_cur), ptr(c_x), ptr(c_y), ptr(c_oct), ptr(c_ang), ptr(c_desc), ptr(c_obs),
+            float(th), int(self.mbCheckOrientation), ptr(cur_match), ptr(nm)))
+        return nm, cur_match
+
+    # ---- SearchByProjection(Frame&, const vector<MapPoint*>&, th) (:64) --------------
+    def _search_mappoints(self, F, vpMapPoints, th=3.0):
+        nmp = len(vpMapPoints)
+        track = np.zeros(max(nmp, 1), np.uint8)
+        level = np.zeros(max(nmp, 1), np.int32)
+        vcos, px, py = (np.zeros(max(nmp, 1), np.float32) for _ in range(3))
+        desc = np.zeros((max(nmp, 1), 32), np.uint8)
+        obs = np.zeros(max(nmp, 1), np.int32)
+        for i, mp in enumerate(vpMapPoints):
+            track[i] = 1 if (mp.mbNeedTrackInView and not mp.isBad()) else 0
+            level[i], vcos[i] = mp.mnTrackedScaleLevel, mp.mTrackedViewCosine
+            px[i], py[i] = mp.mTrackedProjX, mp.mTrackedProjY
+            desc[i], obs[i] = mp.GetDescriptor(), mp.Observations()
+        f_obs = np.full(max(F.N, 1), -1, np.int32)
+        for idx, mp in enumerate(F.mvpMapPoints):
+            if mp is not None:
+                f_obs[idx] = mp.Observations()
+        f_x, f_y = _f32(F.mvKeysUn["x"]), _f32(F.mvKeysUn["y"])
+        f_oct = _i32(F.mvKeysUn["octave"])
+        sf = _f32(F.mvScaleFactors)
+        match = np.full(max(F.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        b = FrameBounds(F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY)
+        check(self._lib.orb_search_by_projection_mappoints(
+            self.device, b, ptr(sf), len(sf), F.N, ptr(f_x), ptr(f_y), ptr(f_oct), ptr(F.mDescriptors), ptr(f_obs),
+            nmp, ptr(track), ptr(level), ptr(vcos), ptr(px), ptr(py), ptr(desc), ptr(obs),
+            float(th), self.mfNNratio, ptr(match), C.byref(nm)))
+        for idx in range(F.N):
+            if match[idx] >= 0:
+                F.mvpMapPoints[idx] = vpMapPoints[match[idx]]
+        return nm.value
+
+    # ---- SearchForTriangulation (:853) ---------------------------------------------
+    def SearchForTriangulation(self, pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo=False):
+        # epipole of KF1's centre in KF2, reference src/ORBmatcher.cc:862-871
+        Cw = pKF1.GetCameraCenter()
+        C2 = _mat3_mul_add(pKF2.GetRotation(), Cw, pKF2.GetTranslation())
+        invz = np.float32(1.0) / C2[2]
+        ex = np.float32(np.float32(np.float32(np.float32(pKF2.fx) * C2[0]) * invz) + np.float32(pKF2.cx))
+        ey = np.float32(np.float32(np.float32(np.float32(pKF2.fy) * C2[1]) * invz) + np.float32(pKF2.cy))
+
+        def flat(fv):
+            nodes = np.array(list(fv.keys()), np.int32)
+            start = np.zeros(len(nodes) + 1, np.int32)
+            items = []
+            for k, v in enumerate(fv.values()):
+                items.extend(v)
+                start[k + 1] = len(items)
+            return nodes, start, np.array(items, np.int32) if items else np.zeros(1, np.int32)
+
+        nd1, st1, it1 = flat(pKF1.mFeatVec)
+        nd2, st2, it2 = flat(pKF2.mFeatVec)
+        k1, k2 = pKF1.mvKeysUn, pKF2.mvKeysUn
+        has1 = np.array([mp is not None for mp in pKF1.mvpMapPoints] or [0], np.uint8)
+        has2 = np.array([mp is not None for mp in pKF2.mvpMapPoints] or [0], np.uint8)
+        m12 = np.full(max(pKF1.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        sf2, ls2 = _f32(pKF2.mvScaleFactors), _f32(pKF2.mvLevelSigma2)
+        F12 = _f32(F12).reshape(9)
+        check(self._lib.orb_search_for_triangulation(
+            self.device, pKF1.N, ptr(_f32(k1["x"])), ptr(_f32(k1["y"])), ptr(_i32(k1["octave"])), ptr(_f32(k1["angle"])),
+            ptr(pKF1.mDescriptors), ptr(has1),
+            pKF2.N, ptr(_f32(k2["x"])), ptr(_f32(k2["y"])), ptr(_i32(k2["octave"])), ptr(_f32(k2["angle"])),
+            ptr(pKF2.mDescriptors), ptr(has2),
+            len(nd1), ptr(nd1), ptr(st1), ptr(it1), len(nd2), ptr(nd2), ptr(st2), ptr(it2),
+            ptr(F12), float(ex), float(ey), ptr(sf2), ptr(ls2), len(sf2), int(self.mbCheckOrientation),
+            ptr(m12), C.byref(nm)))
+        vMatchedPairs.clear()
+        vMatchedPairs.extend((i, int(m12[i])) for i in range(pKF1.N) if m12[i] >= 0)
+        return nm.value
+
+
+def knn2_bruteforce(q, db, ratio=0.7, device=0):
+    """Brute-force Hamming 2-nearest-neighbour search with ratio test on one GPU.
+    Returns (best, second, idx, accept)."""
+    q, db = _u8(q).reshape(-1, 32), _u8(db).reshape(-1, 32)
+    nq = len(q)
+    best, second, idx = (np.zeros(max(nq, 1), np.int32) for _ in range(3))
+    acc = np.zeros(max(nq, 1), np.uint8)
+    check(_lib.lib().orb_knn2_bruteforce(int(device), ptr(q), nq, ptr(db), len(db), float(ratio),
+                                         ptr(best), ptr(second), ptr(idx), ptr(acc)))
+    return best[:nq], second[:nq], idx[:nq], acc[:nq]

@@ -1,0 +1,195 @@
+"""GPU parity of the matcher entry points against the CPU oracle (bit-exact: distances,
+indices and accept decisions are integer work)."""
+import numpy as np
+import pytest
+
+from helpers import flip_bits, kp_struct, projection_scene, random_frame_arrays, scale_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def test_descriptor_distance_kat(oracle):
+    from orb_slam2_amd import ORBmatcher
+    z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert ORBmatcher.DescriptorDistance(z, o) == 256
+    assert ORBmatcher.DescriptorDistance(o, o) == 0
+    one = z.copy(); one[17] = 4
+    assert ORBmatcher.DescriptorDistance(z, one) == 1
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
+    got = ORBmatcher.DescriptorDistances(a, b)
+    want = np.unpackbits(a ^ b, axis=1).sum(1)
+    assert np.array_equal(got, want)
+    assert got[7] == oracle.descriptor_distance(a[7], b[7])
+
+
+@pytest.mark.parametrize("nq,ndb", [(1, 1), (37, 5), (1000, 3000), (2500, 700), (4096, 1024)])
+def test_knn2_vs_oracle(oracle, nq, ndb):
+    from orb_slam2_amd import knn2_bruteforce
+    from orb_slam2_amd.synth import synth_descriptors
+    db, q = synth_descriptors(ndb, nq, seed=nq + ndb)
+    if ndb > 4:
+        db[3] = db[1]  # exact duplicates: the first one must win
+    b, s, i, a = knn2_bruteforce(q, db, 0.7)
+    rb, rs, ri, ra = oracle.knn2_bruteforce(q, db, 0.7)
+    assert np.array_equal(b, rb) and np.array_equal(s, rs) and np.array_equal(i, ri) and np.array_equal(a, ra)
+
+
+def test_knn2_empty_db():
+    from orb_slam2_amd import knn2_bruteforce
+    q = np.zeros((5, 32), np.uint8)
+    b, s, i, a = knn2_bruteforce(q, np.zeros((0, 32), np.uint8), 0.7)
+    assert (b == 256).all() and (s == 256).all() and (i == -1).all() and (a == 0).all()
+
+
+@pytest.mark.parametrize("seed,nl,nc,clusters,ori", [(0, 300, 400, 0, True), (1, 2000, 2000, 0, True),
+                                                      (2, 2000, 1500, 40, True), (3, 1500, 2000, 60, False),
+                                                      (4, 5, 3, 0, True)])
+def test_search_by_projection_frames(oracle, seed, nl, nc, clusters, ori):
+    from orb_slam2_amd import Frame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(seed)
+    sc = projection_scene(rng, nl, nc, 376, 1241, conflict_clusters=clusters)
+    want_n, want_match = oracle.search_by_projection_frames(sc["Tcw"], sc["K"], sc["bounds"], sc["sf"], sc["last"],
+                                                            sc["cur"], 7.0, ori)
+    sf, s2 = scale_tables()
+    L, Cu = sc["last"], sc["cur"]
+    last = Frame(kp_struct(np.zeros(nl), np.zeros(nl), L["octave"], L["angle"]), np.zeros((nl, 32), np.uint8), sf, s2,
+                 sc["K"], sc["bounds"])
+    for i in range(nl):
+        if L["mp_obs"][i] >= 0:
+            last.mvpMapPoints[i] = MapPoint(L["xw"][i], L["mp_desc"][i], L["mp_obs"][i])
+    cur = Frame(kp_struct(Cu["x"], Cu["y"], Cu["octave"], Cu["angle"]), Cu["desc"], sf, s2, sc["K"], sc["bounds"], sc["Tcw"])
+    pre = {}
+    for i2 in range(nc):
+        if Cu["obs"][i2] >= 0:
+            cur.mvpMapPoints[i2] = pre[i2] = MapPoint(np.zeros(3), np.zeros(32, np.uint8), Cu["obs"][i2])
+    got_n = ORBmatcher(0.9, ori).SearchByProjection(cur, last, 7.0, True)
+    assert got_n == want_n
+    for i2 in range(nc):
+        if want_match[i2] >= 0:
+            assert cur.mvpMapPoints[i2] is last.mvpMapPoints[want_match[i2]], i2
+        elif want_match[i2] == -2:
+            assert cur.mvpMapPoints[i2] is None
+        else:
+            assert cur.mvpMapPoints[i2] is pre.get(i2)
+    assert want_n > 0 or nl < 10
+
+
+def test_search_by_projection_frames_batch(oracle):
+    from orb_slam2_amd import Frame, MapPoint, ORBmatcher
+    sf, s2 = scale_tables()
+    curs, lasts, wants = [], [], []
+    for p in range(5):
+        rng = np.random.default_rng(100 + p)
+        nl, nc = 800 + 100 * p, 900 - 50 * p
+        sc = projection_scene(rng, nl, nc, 376, 1241, conflict_clusters=10)
+        wants.append(oracle.search_by_projection_frames(sc["Tcw"], sc["K"], sc["bounds"], sc["sf"], sc["last"], sc["cur"], 7.0, True))
+        L, Cu = sc["last"], sc["cur"]
+        last = Frame(kp_struct(np.zeros(nl), np.zeros(nl), L["octave"], L["angle"]), np.zeros((nl, 32), np.uint8), sf, s2, sc["K"], sc["bounds"])
+        for i in range(nl):
+            if L["mp_obs"][i] >= 0:
+                last.mvpMapPoints[i] = MapPoint(L["xw"][i], L["mp_desc"][i], L["mp_obs"][i])
+        cur = Frame(kp_struct(Cu["x"], Cu["y"], Cu["octave"], Cu["angle"]), Cu["desc"], sf, s2, sc["K"], sc["bounds"], sc["Tcw"])
+        for i2 in range(nc):
+            if Cu["obs"][i2] >= 0:
+                cur.mvpMapPoints[i2] = MapPoint(np.zeros(3), np.zeros(32, np.uint8), Cu["obs"][i2])
+        curs.append(cur); lasts.append(last)
+    nm, match = ORBmatcher(0.9, True).search_by_projection_frames_batch(curs, lasts, 7.0)
+    for p in range(5):
+        assert nm[p] == wants[p][0]
+        assert np.array_equal(match[p, :curs[p].N], wants[p][1])
+
+
+@pytest.mark.parametrize("seed,nmp,nf,th,ratio", [(0, 500, 800, 1.0, 0.8), (1, 3000, 2000, 5.0, 0.8), (2, 2000, 600, 3.0, 0.6)])
+def test_search_by_projection_mappoints(oracle, seed, nmp, nf, th, ratio):
+    from orb_slam2_amd import Frame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(seed)
+    sf, s2 = scale_tables()
+    fx_, fy_, foct, fang, fdesc = random_frame_arrays(rng, nf, 480, 752)
+    # crowd part of the frame so that best and second often share a level and compete
+    m = rng.integers(0, nf, nf // 3)
+    fx_[m] = fx_[m[0]] + rng.uniform(-30, 30, len(m)).astype(np.float32)
+    fy_[m] = fy_[m[0]] + rng.uniform(-30, 30, len(m)).astype(np.float32)
+    src = rng.integers(0, nf, nmp)
+    mps = dict(track=(rng.uniform(0, 1, nmp) < 0.9).astype(np.uint8),
+               level=np.clip(foct[src] + rng.integers(0, 2, nmp), 0, 7).astype(np.int32),
+               viewcos=rng.uniform(0.99, 1.0, nmp).astype(np.float32),
+               projx=(fx_[src] + rng.uniform(-3, 3, nmp)).astype(np.float32),
+               projy=(fy_[src] + rng.uniform(-3, 3, nmp)).astype(np.float32),
+               desc=flip_bits(rng, fdesc[src], 70), obs=rng.integers(0, 3, nmp).astype(np.int32))
+    fobs = np.where(rng.uniform(0, 1, nf) < 0.1, rng.integers(0, 3, nf), -1).astype(np.int32)
+    frame = dict(x=fx_, y=fy_, octave=foct, desc=fdesc, obs=fobs)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    want_n, want_match = oracle.search_by_projection_mappoints(bounds, sf, frame, mps, th, ratio)
+    F = Frame(kp_struct(fx_, fy_, foct, fang), fdesc, sf, s2, (500, 500, 376, 240), bounds)
+    pre = {}
+    for idx in range(nf):
+        if fobs[idx] >= 0:
+            F.mvpMapPoints[idx] = pre[idx] = MapPoint(np.zeros(3), np.zeros(32, np.uint8), fobs[idx])
+    vp = []
+    for i in range(nmp):
+        mp = MapPoint(np.zeros(3), mps["desc"][i], mps["obs"][i])
+        mp.mbNeedTrackInView = bool(mps["track"][i])
+        mp.mnTrackedScaleLevel, mp.mTrackedViewCosine = int(mps["level"][i]), float(mps["viewcos"][i])
+        mp.mTrackedProjX, mp.mTrackedProjY = float(mps["projx"][i]), float(mps["projy"][i])
+        vp.append(mp)
+    got_n = ORBmatcher(ratio, True).SearchByProjection(F, vp, th)
+    assert got_n == want_n and want_n > 0
+    for idx in range(nf):
+        if want_match[idx] >= 0:
+            assert F.mvpMapPoints[idx] is vp[want_match[idx]]
+        else:
+            assert F.mvpMapPoints[idx] is pre.get(idx)
+
+
+@pytest.mark.parametrize("seed,n1,n2,ori", [(0, 600, 700, False), (1, 2000, 2000, False), (2, 1500, 1800, True)])
+def test_search_for_triangulation(oracle, seed, n1, n2, ori):
+    from orb_slam2_amd import KeyFrame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(seed)
+    sf, s2 = scale_tables()
+    rows, cols = 480, 752
+    x2, y2, o2, a2, d2 = random_frame_arrays(rng, n2, rows, cols)
+    src = rng.integers(0, n2, n1)
+    # pure x-translation between the keyframes: epipolar lines are image rows
+    x1 = (x2[src] + rng.uniform(5, 60, n1)).astype(np.float32)
+    y1 = (y2[src] + rng.normal(0, 0.7, n1)).astype(np.float32)
+    o1 = o2[src].copy()
+    a1 = ((a2[src] + rng.normal(0, 6, n1)) % 360).astype(np.float32)
+    d1 = flip_bits(rng, d2[src], 45)
+    K = (np.float32(500), np.float32(500), np.float32(376), np.float32(240))
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) * np.float32(0.002)
+    nnodes = 60
+    node_of2 = rng.integers(0, nnodes, n2)
+    node_of1 = np.where(rng.uniform(0, 1, n1) < 0.8, node_of2[src], rng.integers(0, nnodes + 5, n1))
+    fv1 = {int(k) * 3: [int(i) for i in np.nonzero(node_of1 == k)[0]] for k in np.unique(node_of1)}
+    fv2 = {int(k) * 3: [int(i) for i in np.nonzero(node_of2 == k)[0]] for k in np.unique(node_of2)}
+    has1 = rng.uniform(0, 1, n1) < 0.3
+    has2 = rng.uniform(0, 1, n2) < 0.3
+    T1 = np.eye(4, dtype=np.float32)
+    T2 = np.eye(4, dtype=np.float32); T2[0, 3] = 0.5; T2[2, 3] = 0.3
+    kf1 = KeyFrame(kp_struct(x1, y1, o1, a1), d1, sf, s2, K, (0, cols, 0, rows), T1, feat_vec=fv1)
+    kf2 = KeyFrame(kp_struct(x2, y2, o2, a2), d2, sf, s2, K, (0, cols, 0, rows), T2, feat_vec=fv2)
+    for i in np.nonzero(has1)[0]:
+        kf1.mvpMapPoints[i] = MapPoint(np.zeros(3), d1[i])
+    for i in np.nonzero(has2)[0]:
+        kf2.mvpMapPoints[i] = MapPoint(np.zeros(3), d2[i])
+    pairs = []
+    got_n = ORBmatcher(0.6, ori).SearchForTriangulation(kf1, kf2, F12, pairs, False)
+
+    def flat(fv):
+        nodes = np.array(list(fv.keys()), np.int32); start = [0]; items = []
+        for v in fv.values():
+            items.extend(v); start.append(len(items))
+        return dict(node=nodes, start=np.array(start, np.int32), items=np.array(items, np.int32))
+    from orb_slam2_amd.matcher import _mat3_mul_add
+    C2 = _mat3_mul_add(kf2.GetRotation(), kf1.GetCameraCenter(), kf2.GetTranslation())
+    invz = np.float32(1.0) / C2[2]
+    ex = np.float32(np.float32(np.float32(K[0] * C2[0]) * invz) + K[2])
+    ey = np.float32(np.float32(np.float32(K[1] * C2[1]) * invz) + K[3])
+    want_n, want_m = oracle.search_for_triangulation(
+        dict(x=x1, y=y1, octave=o1, angle=a1, desc=d1, has_mp=has1.astype(np.uint8)),
+        dict(x=x2, y=y2, octave=o2, angle=a2, desc=d2, has_mp=has2.astype(np.uint8)),
+        flat(kf1.mFeatVec), flat(kf2.mFeatVec), F12, (ex, ey), sf, s2, ori)
+    assert got_n == want_n and want_n > 20
+    assert pairs == [(i, int(want_m[i])) for i in range(n1) if want_m[i] >= 0]
