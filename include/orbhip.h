@@ -88,7 +88,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
                       uint8_t* descriptors, int* n_out);
 
 /* The same with every buffer resident on the handle's GPU.  The work is enqueued on
- * `stream` (a hipStream_t; null = the handle's own stream) and not waited for; the
+ * `stream` (a hipStream_t; null = the device's default stream) and not waited for; the
  * call allocates only when the image size or n_frames grows beyond what the handle
  * has already seen.  d_n_out[k] is the count found for frame k (may exceed max_kp,
  * in which case only max_kp entries were written). */
@@ -96,8 +96,19 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
                              int cols, size_t stride, size_t frame_stride, int max_kp,
                              OrbKeyPoint* d_keypoints, uint8_t* d_descriptors, int* d_n_out,
                              void* stream);
-/* Waits for everything enqueued on the handle's own stream. */
+/* Waits for the handle's own stream, which the host-buffer entry points and the
+ * accessors below use. */
 int orb_extractor_sync(OrbExtractor* h);
+
+/* Stage timing of the batch calls (no counterpart in the reference, which has no timers
+ * on this path).  While enabled, every batch call records HIP events on its stream
+ * between the stages; orb_extractor_stage_times waits for those calls and returns the
+ * milliseconds each stage took, averaged over the calls since the times were last
+ * read, in the order {pyramid, FAST, quad-tree, blur, orientation+descriptors}.
+ * Returns the stage count. */
+#define ORBHIP_NUM_STAGES 5
+int orb_extractor_set_profiling(OrbExtractor* h, int enable);
+int orb_extractor_stage_times(OrbExtractor* h, float* ms /* ORBHIP_NUM_STAGES */);
 
 /* mvImagePyramid[level] of the last call (include/ORBextractor.h:166), frame `frame`
  * of the batch.  padded != 0 returns the (h+38) x (w+38) image including the 19-px
@@ -157,6 +168,22 @@ int orb_search_by_projection_frames(
     const int* last_octave, const float* last_angle, const int* n_cur, const float* cur_x,
     const float* cur_y, const int* cur_octave, const float* cur_angle, const uint8_t* cur_desc,
     const int* cur_obs, float th, int check_orientation, int* cur_match, int* n_matches);
+
+/* The same search with every array resident on GPU `device_id`, keypoints given as the
+ * OrbKeyPoint records the extractor writes (only x, y, octave, angle are read; the
+ * last-frame records supply mvKeys[i].octave and mvKeysUn[i].angle).  Pair p uses
+ * d_last_* + p*max_last and d_cur_* + p*max_cur.  scale_factors is a HOST array.
+ * d_scratch must hold orb_match_scratch_bytes(n_pairs, max_last) bytes.  Enqueued on
+ * `stream`, not waited for; allocates nothing. */
+size_t orb_match_scratch_bytes(int n_pairs, int max_queries);
+int orb_search_by_projection_frames_device(
+    int device_id, int n_pairs, int max_last, int max_cur, const float* d_tcw, float fx, float fy,
+    float cx, float cy, OrbFrameBounds bounds, const float* scale_factors, int nlevels,
+    const int* d_n_last, const OrbKeyPoint* d_last_kps, const int* d_last_mp_obs,
+    const float* d_last_xw, const uint8_t* d_last_mp_desc, const int* d_n_cur,
+    const OrbKeyPoint* d_cur_kps, const uint8_t* d_cur_desc, const int* d_cur_obs, float th,
+    int check_orientation, void* d_scratch, size_t scratch_bytes, int* d_cur_match,
+    int* d_n_matches, void* stream);
 
 /* ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>&, th)
  * (src/ORBmatcher.cc:64-158) for one frame.  Per map point: mp_track =

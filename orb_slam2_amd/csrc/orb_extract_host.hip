@@ -72,6 +72,10 @@ struct OrbExtractor {
   int* d_nout = nullptr;
   size_t out_cap = 0;  // frames*max_kp the output staging holds
   int out_frames = 0;
+  // stage timing
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;  // ORBHIP_NUM_STAGES + 1 events per profiled call
+  int prof_calls = 0;          // profiled calls since the times were last read
 };
 
 namespace {
@@ -207,7 +211,7 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   Plan P; std::vector<XTab> xtab; std::vector<YTab> ytab; std::vector<FastItem> fi; std::vector<BlurItem> bi;
   int rc = build_plan(h, rows, cols, P, xtab, ytab, fi, bi);
   if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  ORB_HIP_CHECK(hipDeviceSynchronize());
   const int cap = std::max(nframes, (h->have_plan && h->plan.rows == rows && h->plan.cols == cols) ? h->cap_frames : 0);
   free_plan_buffers(h);
   ORB_HIP_CHECK(hipMalloc(&h->d_pyr, P.slab * cap));
@@ -237,14 +241,31 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
 int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride, size_t frame_stride, int max_kp,
             OrbKeyPoint* d_kps, uint8_t* d_desc, int* d_nout, hipStream_t st) {
   const Plan& P = h->plan;
+  const bool prof = h->profiling;
+  hipEvent_t* ev = nullptr;
+  if (prof) {
+    const size_t need = (size_t)(h->prof_calls + 1) * (ORBHIP_NUM_STAGES + 1);
+    while (h->ev.size() < need) {
+      hipEvent_t e;
+      ORB_HIP_CHECK(hipEventCreate(&e));
+      h->ev.push_back(e);
+    }
+    ev = h->ev.data() + (size_t)h->prof_calls * (ORBHIP_NUM_STAGES + 1);
+  }
   ORB_HIP_CHECK(hipMemsetAsync(h->d_cand_cnt, 0, sizeof(int) * (size_t)P.nlevels * nframes, st));
+  if (prof) ORB_HIP_CHECK(hipEventRecord(ev[0], st));
   launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, nframes, st);
   for (int l = 1; l < P.nlevels; l++) launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
+  if (prof) ORB_HIP_CHECK(hipEventRecord(ev[1], st));
   launch_fast(h->d_pyr, P, h->d_fast_items, (int)h->fast_items.size(), h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
               nframes, st);
+  if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));
   launch_octree(h->d_cand, h->d_cand_cnt, h->d_pnode, h->d_sel, h->d_sel_cnt, P, nframes, st);
+  if (prof) ORB_HIP_CHECK(hipEventRecord(ev[3], st));
   launch_blur(h->d_pyr, h->d_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
+  if (prof) ORB_HIP_CHECK(hipEventRecord(ev[4], st));
   launch_orient_desc(h->d_pyr, h->d_blur, h->d_sel, h->d_sel_cnt, P, d_kps, d_desc, d_nout, max_kp, nframes, st);
+  if (prof) { ORB_HIP_CHECK(hipEventRecord(ev[5], st)); h->prof_calls++; }
   ORB_HIP_CHECK(hipGetLastError());
   h->last_frames = nframes;
   return ORBHIP_OK;
@@ -330,9 +351,10 @@ int orb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini
 void orb_extractor_destroy(OrbExtractor* h) {
   if (!h) return;
   DeviceGuard g(h->device);
-  hipStreamSynchronize(h->stream);
+  hipDeviceSynchronize();
   free_plan_buffers(h);
   hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_nout);
+  for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
   delete h;
 }
@@ -371,8 +393,7 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
   if (n_frames <= 0) return ORBHIP_OK;
   if (rows <= 0 || cols <= 0) {  // empty image: the reference returns without touching its outputs
     DeviceGuard g(h->device);
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    ORB_HIP_CHECK(hipMemsetAsync(d_n_out, 0, sizeof(int) * n_frames, st));
+    ORB_HIP_CHECK(hipMemsetAsync(d_n_out, 0, sizeof(int) * n_frames, (hipStream_t)stream));
     return ORBHIP_OK;
   }
   if (!d_images || !d_keypoints || !d_descriptors || max_kp <= 0 || stride < (size_t)cols) {
@@ -381,8 +402,8 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
   DeviceGuard g(h->device);
   int rc = ensure_plan(h, rows, cols, n_frames);
   if (rc != ORBHIP_OK) return rc;
-  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  return enqueue(h, n_frames, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out, st);
+  return enqueue(h, n_frames, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out,
+                 (hipStream_t)stream);
 }
 
 int orb_extractor_sync(OrbExtractor* h) {
@@ -390,6 +411,32 @@ int orb_extractor_sync(OrbExtractor* h) {
   DeviceGuard g(h->device);
   ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
   return ORBHIP_OK;
+}
+
+int orb_extractor_set_profiling(OrbExtractor* h, int enable) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  h->profiling = enable != 0;
+  h->prof_calls = 0;
+  return ORBHIP_OK;
+}
+
+int orb_extractor_stage_times(OrbExtractor* h, float* ms) {
+  if (!h || !ms) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if (h->prof_calls == 0) { set_error("no profiled call has run"); return ORBHIP_ERR_ARG; }
+  DeviceGuard g(h->device);
+  for (int i = 0; i < ORBHIP_NUM_STAGES; i++) ms[i] = 0.f;
+  for (int c = 0; c < h->prof_calls; c++) {
+    hipEvent_t* ev = h->ev.data() + (size_t)c * (ORBHIP_NUM_STAGES + 1);
+    ORB_HIP_CHECK(hipEventSynchronize(ev[ORBHIP_NUM_STAGES]));
+    for (int i = 0; i < ORBHIP_NUM_STAGES; i++) {
+      float t = 0.f;
+      ORB_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      ms[i] += t;
+    }
+  }
+  for (int i = 0; i < ORBHIP_NUM_STAGES; i++) ms[i] /= (float)h->prof_calls;
+  h->prof_calls = 0;
+  return ORBHIP_NUM_STAGES;
 }
 
 int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int rows, int cols, size_t stride,
@@ -464,7 +511,7 @@ static int copy_level(OrbExtractor* h, const uint8_t* buf, int frame, int level,
   if (!dst) return ORBHIP_OK;
   if (dst_stride < (size_t)w) { set_error("dst_stride too small"); return ORBHIP_ERR_ARG; }
   DeviceGuard g(h->device);
-  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  ORB_HIP_CHECK(hipDeviceSynchronize());
   const uint8_t* src = buf + (size_t)frame * h->plan.slab + L.off +
                        (padded ? (size_t)(kXOff - kEdge) : (size_t)kEdge * L.pitch + kXOff);
   ORB_HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.pitch, w, hh, hipMemcpyDeviceToHost));
@@ -486,7 +533,7 @@ static int fetch_points(OrbExtractor* h, const uint32_t* d_arr, int per_frame, i
   int rc = check_frame_level(h, frame, level);
   if (rc != ORBHIP_OK) return rc;
   DeviceGuard g(h->device);
-  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  ORB_HIP_CHECK(hipDeviceSynchronize());
   int n = 0;
   ORB_HIP_CHECK(hipMemcpy(&n, d_cnt + frame * h->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
   out.resize(n);

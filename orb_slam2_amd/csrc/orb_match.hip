@@ -145,6 +145,8 @@ enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2 };
 
 struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
+  int ts, qs;  // element stride (4-byte units) of t_x/t_y/t_oct/t_angle and of q_oct/q_angle:
+               // 1 for separate arrays, 6 for fields of OrbKeyPoint records
   const int* n_q; const int* n_t;
   // train side (current frame / frame F / keyframe 2)
   const float* t_x; const float* t_y; const int* t_oct; const float* t_angle;
@@ -293,8 +295,8 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   // ---- phase 0: train keypoints to LDS; 64x48 grid as CSR in insertion order
   // (Frame::AssignFeaturesToGrid / PosInGrid, reference src/Frame.cc:190-213, 461-477)
   for (int j = tid; j < nt; j += M_THREADS) {
-    S.kx[j] = A.t_x[tbase + j]; S.ky[j] = A.t_y[tbase + j];
-    S.koct[j] = (unsigned char)A.t_oct[tbase + j];
+    S.kx[j] = A.t_x[(tbase + j) * A.ts]; S.ky[j] = A.t_y[(tbase + j) * A.ts];
+    S.koct[j] = (unsigned char)min(max(A.t_oct[(tbase + j) * A.ts], 0), 255);
     S.occ[j] = (unsigned char)(A.t_obs[tbase + j] > 0);
     if (MODE != MODE_TRIANG) out_match[j] = -1;
   }
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       if (invzc < 0) valid = false;
       const float u = A.fx * xc * invzc + A.cx, v = A.fy * yc * invzc + A.cy;
       if (u < A.b.min_x || u > A.b.max_x || v < A.b.min_y || v > A.b.max_y || isnan(u) || isnan(v)) valid = false;
-      int oct = A.q_oct[qbase + i];
+      int oct = A.q_oct[(qbase + i) * A.qs];
       oct = min(max(oct, 0), A.nlevels - 1);
       geo.x = u; geo.y = v; geo.z = A.th * A.sf[oct];
       geo.w = __int_as_float(((oct - 1 + 1024) & 0xFFFF) | ((oct + 1 + 1024) << 16));
@@ -492,12 +494,12 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
               const int idx1 = A.q_idx1[qbase + i];
               out_match[idx1] = s1;
               A.q_slot[qbase + i] = idx1;
-              if (A.check_ori) A.q_bin[qbase + i] = rot_bin(A.q_angle[qbase + idx1] - A.t_angle[tbase + s1]);
+              if (A.check_ori) A.q_bin[qbase + i] = rot_bin(A.q_angle[qbase + idx1] - A.t_angle[(tbase + s1) * A.ts]);
             } else {
               atomicMax(&out_match[s1], i);  // a later query overwrites an earlier one
               A.q_slot[qbase + i] = s1;
               if (MODE == MODE_FRAMES && A.check_ori)
-                A.q_bin[qbase + i] = rot_bin(A.q_angle[qbase + i] - A.t_angle[tbase + s1]);
+                A.q_bin[qbase + i] = rot_bin(A.q_angle[(qbase + i) * A.qs] - A.t_angle[(tbase + s1) * A.ts]);
             }
           }
         }
@@ -578,20 +580,39 @@ struct DevSel {
     if (rc__ != ORBHIP_OK) return rc__;               \
   } while (0)
 
+constexpr size_t kScratchPerQuery = sizeof(uint2) * MK + sizeof(int) * 3 + sizeof(float4);
+
+void carve_scratch(MatchArgs& A, void* scratch, size_t nq) {
+  unsigned char* p = reinterpret_cast<unsigned char*>(scratch);
+  A.q_geo = reinterpret_cast<float4*>(p); p += sizeof(float4) * nq;
+  A.lists = reinterpret_cast<uint2*>(p); p += sizeof(uint2) * MK * nq;
+  A.q_ntot = reinterpret_cast<int*>(p); p += sizeof(int) * nq;
+  A.q_slot = reinterpret_cast<int*>(p); p += sizeof(int) * nq;
+  A.q_bin = reinterpret_cast<int*>(p);
+}
+
+template <int MODE>
+int launch_match(const MatchArgs& A, int n_pairs, hipStream_t st) {
+  const size_t lds = match_lds_bytes(A.max_t);
+  if (lds > 150 * 1024) { set_error("too many train keypoints for the LDS-resident grid (limit about 11000)"); return ORBHIP_ERR_UNSUPPORTED; }
+  if (lds > 64 * 1024)
+    ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_kernel<MODE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(match_kernel<MODE>, dim3(n_pairs), dim3(M_THREADS), lds, st, A);
+  ORB_HIP_CHECK(hipGetLastError());
+  return ORBHIP_OK;
+}
+
 template <int MODE>
 int run_match(MatchArgs& A, int n_pairs, DevBuf& buf) {
   const size_t nq = (size_t)n_pairs * A.max_q;
-  UP(buf, (const uint2*)nullptr, nq * MK, A.lists);
-  UP(buf, (const int*)nullptr, nq, A.q_ntot);
-  UP(buf, (const float4*)nullptr, nq, A.q_geo);
-  UP(buf, (const int*)nullptr, nq, A.q_slot);
-  UP(buf, (const int*)nullptr, nq, A.q_bin);
-  const size_t lds = match_lds_bytes(A.max_t);
-  if (lds > 150 * 1024) { set_error("too many train keypoints for the LDS-resident grid (limit about 11000)"); return ORBHIP_ERR_UNSUPPORTED; }
-  ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_kernel<MODE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(match_kernel<MODE>, dim3(n_pairs), dim3(M_THREADS), lds, 0, A);
-  ORB_HIP_CHECK(hipGetLastError());
+  unsigned char* scratch;
+  UP(buf, (const unsigned char*)nullptr, nq * kScratchPerQuery + 64, scratch);
+  carve_scratch(A, scratch, nq);
+  if (A.ts == 0) A.ts = 1;
+  if (A.qs == 0) A.qs = 1;
+  int rc = launch_match<MODE>(A, n_pairs, 0);
+  if (rc != ORBHIP_OK) return rc;
   ORB_HIP_CHECK(hipDeviceSynchronize());
   return ORBHIP_OK;
 }
@@ -698,6 +719,45 @@ int orb_search_by_projection_frames(int device_id, int n_pairs, int max_last, in
   ORB_HIP_CHECK(hipMemcpy(cur_match, A.out_match, sizeof(int) * nt, hipMemcpyDeviceToHost));
   ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int) * n_pairs, hipMemcpyDeviceToHost));
   return ORBHIP_OK;
+}
+
+size_t orb_match_scratch_bytes(int n_pairs, int max_queries) {
+  if (n_pairs <= 0 || max_queries <= 0) return 64;
+  return (size_t)n_pairs * max_queries * kScratchPerQuery + 64;
+}
+
+int orb_search_by_projection_frames_device(int device_id, int n_pairs, int max_last, int max_cur, const float* d_tcw,
+                                           float fx, float fy, float cx, float cy, OrbFrameBounds bounds,
+                                           const float* scale_factors, int nlevels, const int* d_n_last,
+                                           const OrbKeyPoint* d_last_kps, const int* d_last_mp_obs,
+                                           const float* d_last_xw, const uint8_t* d_last_mp_desc, const int* d_n_cur,
+                                           const OrbKeyPoint* d_cur_kps, const uint8_t* d_cur_desc,
+                                           const int* d_cur_obs, float th, int check_orientation, void* d_scratch,
+                                           size_t scratch_bytes, int* d_cur_match, int* d_n_matches, void* stream) {
+  if (n_pairs <= 0) return ORBHIP_OK;
+  if (max_last <= 0 || max_cur <= 0 || max_cur > 65535 || nlevels < 1 || nlevels > kMaxLevels) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
+  if (!d_tcw || !scale_factors || !d_n_last || !d_last_kps || !d_last_mp_obs || !d_last_xw || !d_last_mp_desc ||
+      !d_n_cur || !d_cur_kps || !d_cur_desc || !d_cur_obs || !d_scratch || !d_cur_match || !d_n_matches) {
+    set_error("null argument"); return ORBHIP_ERR_ARG;
+  }
+  if (scratch_bytes < orb_match_scratch_bytes(n_pairs, max_last)) { set_error("scratch too small"); return ORBHIP_ERR_CAPACITY; }
+  if (((uintptr_t)d_last_mp_desc | (uintptr_t)d_cur_desc | (uintptr_t)d_scratch) & 15) { set_error("descriptor and scratch arrays must be 16-byte aligned"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  MatchArgs A{};
+  A.max_q = max_last; A.max_t = max_cur; A.nlevels = nlevels; A.check_ori = check_orientation;
+  A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.b = bounds; A.th = th;
+  for (int i = 0; i < nlevels; i++) A.sf[i] = scale_factors[i];
+  A.ts = A.qs = (int)(sizeof(OrbKeyPoint) / 4);
+  A.n_q = d_n_last; A.n_t = d_n_cur; A.tcw = d_tcw;
+  A.q_obs = d_last_mp_obs; A.q_xw = d_last_xw; A.q_desc = d_last_mp_desc;
+  A.q_oct = &reinterpret_cast<const int*>(d_last_kps)[5];
+  A.q_angle = &reinterpret_cast<const float*>(d_last_kps)[3];
+  const float* ck = reinterpret_cast<const float*>(d_cur_kps);
+  A.t_x = ck; A.t_y = ck + 1; A.t_angle = ck + 3; A.t_oct = reinterpret_cast<const int*>(ck) + 5;
+  A.t_desc = d_cur_desc; A.t_obs = d_cur_obs;
+  A.out_match = d_cur_match; A.n_matches = d_n_matches;
+  carve_scratch(A, d_scratch, (size_t)n_pairs * max_last);
+  return launch_match<MODE_FRAMES>(A, n_pairs, (hipStream_t)stream);
 }
 
 int orb_search_by_projection_mappoints(int device_id, OrbFrameBounds bounds, const float* scale_factors, int nlevels,

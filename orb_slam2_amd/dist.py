@@ -1,0 +1,61 @@
+"""Multi-GPU Hamming kNN-2: the database is split into contiguous row shards (one per
+rank, ascending), every rank scans its shard for all queries, the per-query
+(best, second, index) triples are exchanged with one all-gather and merged.  Shards are
+in index order, so "earlier shard keeps ties" reproduces the single scan's first-minimum
+rule and the merged result equals a one-GPU search bit for bit.
+
+The reference has no multi-device code; this is the one path here with a real exchange
+step.  Frame batches need no communication (each rank extracts its own frames).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows, world, rank):
+    """Contiguous, ascending, near-equal row ranges: [lo, hi) of `rank`."""
+    return n_rows * rank // world, n_rows * (rank + 1) // world
+
+
+def knn2_sharded(local_search, merge, n_q, device, world, group=None):
+    """local_search() -> int32 tensor [3, n_q] (best, second, global index) for this rank's
+    shard; merge(g) with g int32 [3, world, n_q] -> (int32 [3, n_q], uint8 [n_q] accept).
+    Returns the merged tensors (identical on every rank)."""
+    res = local_search()
+    assert res.shape == (3, n_q) and res.dtype == torch.int32
+    if world > 1:
+        gathered = torch.empty((world * 3, n_q), dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(gathered, res.contiguous(), group=group)
+        g = gathered.view(world, 3, n_q).permute(1, 0, 2).contiguous()
+    else:
+        g = res.reshape(3, 1, n_q)
+    return merge(g)
+
+
+def hip_local_search(d_q, d_db_shard, index_base, ratio, device_index, stream=0):
+    """Closure running orb_knn2_device on this rank's shard."""
+    from . import _lib
+    L = _lib.lib()
+    n_q, n_db = d_q.shape[0], d_db_shard.shape[0]
+    res = torch.empty((3, n_q), dtype=torch.int32, device=d_q.device)
+
+    def run():
+        _lib.check(L.orb_knn2_device(device_index, d_q.data_ptr(), n_q, d_db_shard.data_ptr(), n_db, index_base,
+                                     ratio, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), None, stream))
+        return res
+    return run
+
+
+def hip_merge(ratio, device_index, stream=0):
+    """Closure running orb_knn2_merge_device."""
+    from . import _lib
+    L = _lib.lib()
+
+    def run(g):
+        _, world, n_q = g.shape
+        out = torch.empty((3, n_q), dtype=torch.int32, device=g.device)
+        acc = torch.empty(n_q, dtype=torch.uint8, device=g.device)
+        _lib.check(L.orb_knn2_merge_device(device_index, world, n_q, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                                           ratio, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                           acc.data_ptr(), stream))
+        return out, acc
+    return run
