@@ -15,7 +15,7 @@ namespace orbhip {
 void launch_pyr_level0(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, int, hipStream_t);
 void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
 void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, uint32_t*, int*, int, int, int, hipStream_t);
-void launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, hipStream_t);
+hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, int, hipStream_t);
 void launch_blur(const uint8_t*, uint8_t*, const Plan&, const BlurItem*, int, const int*, int, hipStream_t);
 void launch_orient_desc(const uint8_t*, const uint8_t*, const uint32_t*, const int*, const Plan&, OrbKeyPoint*,
                         uint8_t*, int*, int, int, hipStream_t);
@@ -54,6 +54,7 @@ struct OrbExtractor {
   bool have_plan = false;
   int cap_frames = 0;  // frames the buffers can hold
   int last_frames = 0;
+  int ot_slots = 0;    // quad-tree node slots the largest level needs
   std::vector<FastItem> fast_items;
   std::vector<BlurItem> blur_items;
   // device buffers
@@ -234,6 +235,9 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   ORB_HIP_CHECK(hipMemsetAsync(h->d_sel_cnt, 0, sizeof(int) * (size_t)P.nlevels * cap, h->stream));
   ORB_HIP_CHECK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
   h->plan = P; h->fast_items = fi; h->blur_items = bi;
+  h->ot_slots = 0;
+  for (int l = 0; l < P.nlevels; l++)
+    h->ot_slots = std::max(h->ot_slots, std::max(P.lv[l].quota + 3, 4 * P.lv[l].nIni) + P.lv[l].nIni + 8);
   h->have_plan = true; h->cap_frames = cap; h->last_frames = 0;
   return ORBHIP_OK;
 }
@@ -260,7 +264,7 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   launch_fast(h->d_pyr, P, h->d_fast_items, (int)h->fast_items.size(), h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
               nframes, st);
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));
-  launch_octree(h->d_cand, h->d_cand_cnt, h->d_pnode, h->d_sel, h->d_sel_cnt, P, nframes, st);
+  ORB_HIP_CHECK(launch_octree(h->d_cand, h->d_cand_cnt, h->d_pnode, h->d_sel, h->d_sel_cnt, P, h->ot_slots, nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[3], st));
   launch_blur(h->d_pyr, h->d_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[4], st));

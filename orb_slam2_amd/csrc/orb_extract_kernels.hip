@@ -287,8 +287,8 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
 // addresses grew with allocation order (later-created node first).
 // ---------------------------------------------------------------------------
 constexpr int OT_THREADS = 512;
-constexpr int OT_MAXS = 1024;  // node slots
 
+template <int OT_MAXS>  // node slots
 struct OtShared {
   short x0[OT_MAXS], x1[OT_MAXS], y0[OT_MAXS], y1[OT_MAXS];
   int count[OT_MAXS];
@@ -305,12 +305,14 @@ struct OtShared {
 };
 enum { V_SIZE = 0, V_NSLOTS, V_NEXTSEQ, V_MODE, V_FINISH, V_NE, V_NEWEXP, V_PN, V_GROW, V_NCHILD };
 
+template <int OT_MAXS>
 __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __restrict__ cand_all,
                                                             const int* __restrict__ cand_cnt,
                                                             uint32_t* __restrict__ pnode_all,
                                                             uint32_t* __restrict__ sel_all,
                                                             int* __restrict__ sel_cnt, Plan P) {
-  __shared__ OtShared S;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ot_smem[];
+  OtShared<OT_MAXS>& S = *reinterpret_cast<OtShared<OT_MAXS>*>(ot_smem);
   const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   const LevelGeom& L = P.lv[l];
   const uint32_t* pts = cand_all + (size_t)f * P.cand_total + L.cand_off;
@@ -708,10 +710,28 @@ void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int n
   hipLaunchKernelGGL(fast_kernel, dim3(nitems, nframes), dim3(F_THREADS), 0, st, pyr, P, items, cand, cand_cnt, iniTh,
                      minTh);
 }
-void launch_octree(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel, int* sel_cnt,
-                   const Plan& P, int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(octree_kernel, dim3(P.nlevels, nframes), dim3(OT_THREADS), 0, st, cand, cand_cnt, pnode, sel,
-                     sel_cnt, P);
+template <int MAXS>
+static hipError_t launch_octree_t(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel,
+                                  int* sel_cnt, const Plan& P, int nframes, hipStream_t st) {
+  const size_t lds = sizeof(OtShared<MAXS>);
+  if (lds > 64 * 1024) {
+    static bool raised = false;  // per process; the attribute belongs to the function, not the call
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&octree_kernel<MAXS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(octree_kernel<MAXS>, dim3(P.nlevels, nframes), dim3(OT_THREADS), lds, st, cand, cand_cnt, pnode,
+                     sel, sel_cnt, P);
+  return hipSuccess;
+}
+// slots: enough for the largest level (quota + 3 nodes, dead root slots, slack)
+hipError_t launch_octree(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel, int* sel_cnt,
+                         const Plan& P, int max_slots_needed, int nframes, hipStream_t st) {
+  if (max_slots_needed <= 1024) return launch_octree_t<1024>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
+  return launch_octree_t<2048>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
 }
 void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurItem* items, int nitems, const int* taps,
                  int nframes, hipStream_t st) {
@@ -728,7 +748,7 @@ void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t*
 int fast_use_width() { return F_USEW; }
 int fast_max_cells() { return F_MAXCELLS; }
 int fast_max_view_h() { return F_MAXH; }
-int octree_max_slots() { return OT_MAXS; }
+int octree_max_slots() { return 2048; }
 int blur_tile_w() { return B_TW; }
 int blur_tile_h() { return B_TH; }
 

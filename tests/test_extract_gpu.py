@@ -45,7 +45,8 @@ def check_stages(ex, ref, nlevels, frame=0):
     (480, 752, 1200, 1),      # EuRoC right eye
     (240, 320, 500, 5),
     (211, 333, 300, 2),       # odd sizes
-    (97, 131, 4000, 3),       # more features wanted than corners exist (smallest level 27x36? no: >= 62 px needed)
+    (97, 131, 1500, 3),       # more features wanted than corners exist: every candidate survives
+    (480, 640, 8000, 4),      # 2 x 4000 features, the reference's initialisation extractor (src/Tracking.cc:182)
 ])
 def test_extract_matches_oracle(oracle, rows, cols, nf, seed):
     from orb_slam2_amd import ORBextractor
@@ -57,6 +58,8 @@ def test_extract_matches_oracle(oracle, rows, cols, nf, seed):
     kps, desc = ex(img)
     rk, rd = ref(img)
     assert len(rk) > 50
+    if nf == 1500:
+        assert len(rk) < 1500
     check_against(kps, desc, rk, rd)
     check_stages(ex, ref, nlevels)
 
@@ -178,7 +181,7 @@ def test_device_resident_path_and_reuse(oracle):
     dev = torch.device("cuda", 0)
     ex = ORBextractor(500, 1.2, 8, 20, 7)
     ref = oracle.Extractor(500, 1.2, 8, 20, 7)
-    for (rows, cols, n) in [(240, 320, 4), (240, 320, 2), (200, 260, 3)]:
+    for (rows, cols, n) in [(240, 320, 4), (240, 320, 2), (250, 330, 3)]:
         seq = synth_sequence(rows, cols, n, seed=rows + n)
         d_img = torch.from_numpy(seq).to(dev)
         cap = ex.max_keypoints(rows, cols)
