@@ -46,6 +46,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("liborbhip.so not built: run `make -C orb_slam2_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  If it is going to be used in
+    # this process it has to be loaded first, so that this library binds to the same
+    # runtime instead of bringing in a second one from /opt/rocm (torch then finds no GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.orb_last_error.restype = C.c_char_p

@@ -19,6 +19,12 @@ hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*
 void launch_blur(const uint8_t*, uint8_t*, const Plan&, const BlurItem*, int, const int*, int, hipStream_t);
 void launch_orient_desc(const uint8_t*, const uint8_t*, const uint32_t*, const int*, const Plan&, OrbKeyPoint*,
                         uint8_t*, int*, int, int, hipStream_t);
+void launch_pyr_resize_tile(uint8_t*, const Plan&, int, const uint32_t*, const YTab*, const int2*, int, const int2*, int,
+                            int, hipStream_t);
+int pyr_tile_cols();
+int pyr_tile_rows();
+int pyr_tile_max_src_rows();
+int pyr_tile_max_src_bytes();
 int fast_use_width();
 int fast_max_cells();
 int fast_max_view_h();
@@ -55,6 +61,12 @@ struct OrbExtractor {
   int cap_frames = 0;  // frames the buffers can hold
   int last_frames = 0;
   int ot_slots = 0;    // quad-tree node slots the largest level needs
+  // tiled resize: per level, packed column table (one entry per slab column) and the
+  // source ranges of every tile column / tile row; tile_ok[l] = the tiled kernel applies
+  struct TileInfo { bool ok = false; int xtp_off = 0, xr_off = 0, yr_off = 0, ngx = 0, ngy = 0; };
+  TileInfo tile[kMaxLevels];
+  uint32_t* d_xtp = nullptr;
+  int2* d_ranges = nullptr;
   std::vector<FastItem> fast_items;
   std::vector<BlurItem> blur_items;
   // device buffers
@@ -85,6 +97,8 @@ void free_plan_buffers(OrbExtractor* h) {
   hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_xtab); hipFree(h->d_ytab);
   hipFree(h->d_fast_items); hipFree(h->d_blur_items); hipFree(h->d_cand); hipFree(h->d_pnode);
   hipFree(h->d_sel); hipFree(h->d_cand_cnt); hipFree(h->d_sel_cnt);
+  hipFree(h->d_xtp); hipFree(h->d_ranges);
+  h->d_xtp = nullptr; h->d_ranges = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_xtab = nullptr; h->d_ytab = nullptr;
   h->d_fast_items = nullptr; h->d_blur_items = nullptr;
   h->d_cand = h->d_pnode = h->d_sel = nullptr; h->d_cand_cnt = h->d_sel_cnt = nullptr;
@@ -227,6 +241,53 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_ytab, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice, h->stream));
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_fast_items, fi.data(), sizeof(FastItem) * fi.size(), hipMemcpyHostToDevice, h->stream));
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_blur_items, bi.data(), sizeof(BlurItem) * bi.size(), hipMemcpyHostToDevice, h->stream));
+  {
+    // tables of the tiled resize kernel
+    std::vector<uint32_t> xtp;
+    std::vector<int2> ranges;
+    for (int l = 1; l < P.nlevels; l++) {
+      const LevelGeom& L = P.lv[l];
+      const LevelGeom& S = P.lv[l - 1];
+      OrbExtractor::TileInfo ti;
+      ti.xtp_off = (int)xtp.size();
+      const int TC = pyr_tile_cols(), TR = pyr_tile_rows();
+      ti.ngx = (L.pitch + TC - 1) / TC;
+      ti.ngy = (L.h + 2 * kEdge + TR - 1) / TR;
+      auto refl = [](int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; };
+      const int ncol = ti.ngx * TC;
+      std::vector<int2> xr(ti.ngx, make_int2(1 << 30, -1)), yr(ti.ngy, make_int2(1 << 30, -1));
+      for (int c = 0; c < ncol; c++) {
+        const int px = c - kXOff;
+        uint32_t e = 0xFFFF0000u;
+        if (c < L.pitch && px >= -kEdge && px < L.w + kEdge) {
+          const XTab& t = xtab[L.xtab_off + refl(px, L.w)];
+          e = (uint32_t)t.sx | ((uint32_t)(uint16_t)t.a1 << 16);
+          int2& r = xr[c / TC];
+          r.x = std::min(r.x, (int)t.sx); r.y = std::max(r.y, (int)t.sx + 1);
+        }
+        xtp.push_back(e);
+      }
+      for (int r = 0; r < L.h + 2 * kEdge; r++) {
+        const YTab& t = ytab[L.ytab_off + refl(r - kEdge, L.h)];
+        int2& q = yr[r / TR];
+        q.x = std::min(q.x, (int)std::min(t.sy0, t.sy1)); q.y = std::max(q.y, (int)std::max(t.sy0, t.sy1));
+      }
+      ti.ok = true;
+      for (int2& r : xr) {
+        if (r.y < 0) { r.x = 0; r.y = 0; }
+        const int a0 = (r.x + kXOff) & ~15;
+        if (r.y + kXOff - a0 + 16 > pyr_tile_max_src_bytes() || r.y + kXOff + 16 > S.pitch) ti.ok = false;
+      }
+      for (int2& r : yr) if (r.y - r.x + 1 > pyr_tile_max_src_rows()) ti.ok = false;
+      ti.xr_off = (int)ranges.size(); ranges.insert(ranges.end(), xr.begin(), xr.end());
+      ti.yr_off = (int)ranges.size(); ranges.insert(ranges.end(), yr.begin(), yr.end());
+      h->tile[l] = ti;
+    }
+    ORB_HIP_CHECK(hipMalloc(&h->d_xtp, sizeof(uint32_t) * std::max<size_t>(xtp.size(), 4)));
+    ORB_HIP_CHECK(hipMalloc(&h->d_ranges, sizeof(int2) * std::max<size_t>(ranges.size(), 1)));
+    ORB_HIP_CHECK(hipMemcpy(h->d_xtp, xtp.data(), sizeof(uint32_t) * xtp.size(), hipMemcpyHostToDevice));
+    ORB_HIP_CHECK(hipMemcpy(h->d_ranges, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice));
+  }
   ORB_HIP_CHECK(hipMalloc(&h->d_cand, sizeof(uint32_t) * (size_t)P.cand_total * cap));
   ORB_HIP_CHECK(hipMalloc(&h->d_pnode, sizeof(uint32_t) * (size_t)P.cand_total * cap));
   ORB_HIP_CHECK(hipMalloc(&h->d_sel, sizeof(uint32_t) * (size_t)P.sel_total * cap));
@@ -259,7 +320,14 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   ORB_HIP_CHECK(hipMemsetAsync(h->d_cand_cnt, 0, sizeof(int) * (size_t)P.nlevels * nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[0], st));
   launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, nframes, st);
-  for (int l = 1; l < P.nlevels; l++) launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
+  for (int l = 1; l < P.nlevels; l++) {
+    const OrbExtractor::TileInfo& ti = h->tile[l];
+    if (ti.ok)
+      launch_pyr_resize_tile(h->d_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off, ti.ngx,
+                             h->d_ranges + ti.yr_off, ti.ngy, nframes, st);
+    else
+      launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
+  }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[1], st));
   launch_fast(h->d_pyr, P, h->d_fast_items, (int)h->fast_items.size(), h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
               nframes, st);

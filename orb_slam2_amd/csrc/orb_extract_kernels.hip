@@ -79,6 +79,86 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ p
   *reinterpret_cast<uint32_t*>(pyr + (size_t)f * slab + Ld.off + (size_t)row * Ld.pitch + c4) = out;
 }
 
+// Tiled form of the resize for scale factors up to about 1.45: a workgroup produces
+// PR_TR padded rows x PR_TC slab columns.  The source rows it needs are staged in LDS
+// with 16-byte loads; a thread owns 4 adjacent output columns (one dword store per
+// row), reads its taps from LDS and reuses the horizontal result of a source row
+// when the next output row starts on it.  xtp[] holds, per SLAB column, the source
+// column and the second tap's weight (first weight = 2048 - it; 0xFFFF marks columns
+// outside the 19-px frame, which are written as 0).
+constexpr int PR_TC = 1024, PR_TR = 16, PR_THREADS = 256;
+constexpr int PR_SROWS = 32, PR_SPITCH = 1536;
+
+__global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __restrict__ pyr,
+                                                                     unsigned long long slab, LevelGeom Ls,
+                                                                     LevelGeom Ld, const uint32_t* __restrict__ xtp,
+                                                                     const YTab* __restrict__ yt,
+                                                                     const int2* __restrict__ xrange,
+                                                                     const int2* __restrict__ yrange) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[PR_SROWS * PR_SPITCH];
+  const int gx = blockIdx.x, gy = blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
+  const int2 X = xrange[gx], Y = yrange[gy];
+  const int a0 = (X.x + kXOff) & ~15;                  // first staged slab column
+  const int n16 = (X.y + kXOff - a0 + 16) >> 4;        // 16-byte pieces per row
+  const int nrows = Y.y - Y.x + 1;
+  const uint8_t* src = pyr + (size_t)f * slab + Ls.off + (size_t)(Y.x + kEdge) * Ls.pitch + a0;
+  for (int r = tid >> 6; r < nrows; r += PR_THREADS / 64)
+    for (int c = tid & 63; c < n16; c += 64)
+      *reinterpret_cast<uint4*>(&s_src[r * PR_SPITCH + 16 * c]) =
+          *reinterpret_cast<const uint4*>(src + (size_t)r * Ls.pitch + 16 * c);
+  __syncthreads();
+  const int c = gx * PR_TC + 4 * tid;
+  if (c >= Ld.pitch) return;
+  const uint4 e = *reinterpret_cast<const uint4*>(&xtp[c]);
+  const uint32_t ev[4] = {e.x, e.y, e.z, e.w};
+  int col[4], w0[4], w1[4];
+  bool valid[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int a1 = (int)(ev[k] >> 16);
+    valid[k] = a1 != 0xFFFF;
+    col[k] = valid[k] ? (int)(ev[k] & 0xFFFF) + kXOff - a0 : 0;
+    w1[k] = valid[k] ? a1 : 0;
+    w0[k] = valid[k] ? 2048 - a1 : 0;
+  }
+  int hprev[4] = {0, 0, 0, 0};
+  int prev_row = -1;  // source row whose horizontal result is in hprev
+  uint8_t* dst = pyr + (size_t)f * slab + Ld.off + c;
+  const int rend = min(gy * PR_TR + PR_TR, Ld.h + 2 * kEdge);
+  for (int r = gy * PR_TR; r < rend; r++) {
+    const YTab ty = yt[refl101(r - kEdge, Ld.h)];
+    const int s0 = ty.sy0, s1 = ty.sy1;
+    int h0[4], h1[4];
+    if (s0 == prev_row) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) h0[k] = hprev[k];
+    } else {
+      const uint8_t* R = &s_src[(s0 - Y.x) * PR_SPITCH];
+#pragma unroll
+      for (int k = 0; k < 4; k++) h0[k] = R[col[k]] * w0[k] + R[col[k] + 1] * w1[k];
+    }
+    if (s1 == s0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) h1[k] = h0[k];
+    } else {
+      const uint8_t* R = &s_src[(s1 - Y.x) * PR_SPITCH];
+#pragma unroll
+      for (int k = 0; k < 4; k++) h1[k] = R[col[k]] * w0[k] + R[col[k] + 1] * w1[k];
+    }
+    const int b0 = ty.b0, b1 = ty.b1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int v = (((b0 * (h0[k] >> 4)) >> 16) + ((b1 * (h1[k] >> 4)) >> 16) + 2) >> 2;
+      v = min(max(v, 0), 255);
+      out |= (uint32_t)v << (8 * k);
+      hprev[k] = h1[k];
+    }
+    prev_row = s1;
+    *reinterpret_cast<uint32_t*>(dst + (size_t)r * Ld.pitch) = out;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // FAST-9/16 per cell with the iniThFAST -> minThFAST fallback and cell-local
 // 3x3 non-maximum suppression (reference src/ORBextractor.cc:1077-1146 calling
@@ -705,6 +785,15 @@ void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, c
   hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, st, pyr, P.slab, P.lv[level - 1], Ld, xt + Ld.xtab_off,
                      yt + Ld.ytab_off);
 }
+void launch_pyr_resize_tile(uint8_t* pyr, const Plan& P, int level, const uint32_t* xtp, const YTab* yt,
+                            const int2* xrange, int ngx, const int2* yrange, int ngy, int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(pyr_resize_tile_kernel, dim3(ngx, ngy, nframes), dim3(PR_THREADS), 0, st, pyr, P.slab,
+                     P.lv[level - 1], P.lv[level], xtp, yt + P.lv[level].ytab_off, xrange, yrange);
+}
+int pyr_tile_cols() { return PR_TC; }
+int pyr_tile_rows() { return PR_TR; }
+int pyr_tile_max_src_rows() { return PR_SROWS; }
+int pyr_tile_max_src_bytes() { return PR_SPITCH; }
 void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, uint32_t* cand, int* cand_cnt,
                  int iniTh, int minTh, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(fast_kernel, dim3(nitems, nframes), dim3(F_THREADS), 0, st, pyr, P, items, cand, cand_cnt, iniTh,
