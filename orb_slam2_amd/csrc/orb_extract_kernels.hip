@@ -174,7 +174,9 @@ constexpr int F_USEW = 256;   // widest run of cell interiors per workgroup
 constexpr int F_PITCH = 272;  // LDS row pitch: F_USEW + 6 halo + 3 alignment, rounded up
 constexpr int F_MAXH = 66;    // tallest cell view (hCell <= 59, + 6)
 constexpr int F_MAXCELLS = 16;
-constexpr int F_BAND = 2048;
+constexpr int F_QROWS = 16;           // rows per band of a wavefront's queue
+constexpr int F_QCAP = 64 * F_QROWS;  // every pixel of the band may pass the quick test
+constexpr int F_CCAP = 512;           // corners kept per wavefront before falling back to a dense sweep
 
 __device__ __forceinline__ int fast_v(const uint8_t* p /* centre in LDS */) {
   const int c = p[0];
@@ -218,19 +220,31 @@ __device__ __forceinline__ int fast_v(const uint8_t* p /* centre in LDS */) {
   return max(a, -b);
 }
 
+// NMS decision for the pixel whose V byte is at q: strictly greater than the 8
+// neighbours' scores, where neighbours in another cell (hasL / hasR false) or on the
+// 3-px rim (V byte 0) count as 0.  Scores are V - 1, so "score > 0" is "V >= 2".
+__device__ __forceinline__ bool fast_nms_keep(const uint8_t* q, int v, bool hasL, bool hasR) {
+  bool keep = v > q[-F_PITCH] && v > q[F_PITCH];
+  if (hasL) keep = keep && v > q[-1] && v > q[-F_PITCH - 1] && v > q[F_PITCH - 1];
+  if (hasR) keep = keep && v > q[1] && v > q[-F_PITCH + 1] && v > q[F_PITCH + 1];
+  return keep;
+}
+
 __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
                                                          const FastItem* __restrict__ items,
                                                          uint32_t* __restrict__ cand_all,
                                                          int* __restrict__ cand_cnt, int iniTh, int minTh) {
   __shared__ __attribute__((aligned(16))) uint8_t s_img[F_MAXH * F_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t s_v[F_MAXH * F_PITCH];
-  __shared__ uint16_t s_list[F_BAND];
+  __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];  // per wavefront: quick-test survivors of a band
+  __shared__ uint16_t s_corner[F_THREADS / 64][F_CCAP];  // per wavefront: corners (V > t) of the tile
+  __shared__ int s_ncorner[F_THREADS / 64];
   __shared__ int s_cnt[F_MAXCELLS];
-  __shared__ int s_nlist, s_total, s_base, s_emit;
+  __shared__ int s_total, s_base, s_emit;
 
   const FastItem item = items[blockIdx.x];
   const int f = blockIdx.y;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LevelGeom& L = P.lv[item.level];
   const int wCell = L.wCell, hCell = L.hCell;
   const int iniY = kBorder + item.row * hCell;
@@ -238,71 +252,101 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   const int xb = kBorder + item.j0 * wCell;
   const int xe = min(kBorder + (item.j0 + item.ncells) * wCell + 6, L.maxBX);
   const int tw = xe - xb, th = maxY - iniY;
-  const int wi = tw - 6, hi = th - 6;  // interior (pixels that can be corners)
+  const int wi = tw - 6, hi = th - 6;  // interior (pixels that can be corners); wi <= F_USEW
   if (wi <= 0 || hi <= 0) return;      // uniform: a view shorter than 7 rows yields nothing
 
-  // stage the view, dword-aligned on the slab
+  // stage the view, dword-aligned on the slab: a wave per row
   const int a0 = (xb + kXOff) & ~3;
   const int shift = (xb + kXOff) - a0;
   const int ndw = (shift + tw + 3) >> 2;
   const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(iniY + kEdge) * L.pitch + a0;
-  for (int i = tid; i < th * ndw; i += F_THREADS) {
-    const int r = i / ndw, c = i - r * ndw;
-    *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * c]) =
-        *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * c);
-  }
-  for (int i = tid; i < (F_MAXH * F_PITCH) / 4; i += F_THREADS) reinterpret_cast<uint32_t*>(s_v)[i] = 0;
+  for (int r = wave; r < th; r += F_THREADS / 64)
+    for (int c = lane; c < ndw; c += 64) {
+      *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * c]) =
+          *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * c);
+      *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * c]) = 0;
+    }
   if (tid < F_MAXCELLS) s_cnt[tid] = 0;
   __syncthreads();
 
-  const int npix = wi * hi;
+  // a thread owns interior column x = tid
+  const int x = tid;
+  const bool incol = x < wi;
+  const int cj = incol ? x / wCell : 0;
+  const int colo = x + 3 + shift;  // LDS column of this thread's pixels
+  const unsigned long long lt_mask = (1ull << lane) - 1;
+
   unsigned cellmask = (1u << item.ncells) - 1;  // cells to (re)compute in this pass
+  int ncorner = 0;                              // wave-uniform: entries in this wave's corner list
+  bool overflow = false;                        // wave-uniform: corner list too small, sweep densely
   for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? iniTh : minTh;
-    // ---- V map for the masked cells, in bands: quick reject -> compact -> full test
-    for (int band = 0; band < npix; band += F_BAND) {
-      if (tid == 0) s_nlist = 0;
-      __syncthreads();
-      for (int i = band + tid; i < min(band + F_BAND, npix); i += F_THREADS) {
-        const int y = i / wi, x = i - y * wi;
-        bool ok = false;
-        if ((cellmask >> (x / wCell)) & 1u) {
-          const uint8_t* p = &s_img[(y + 3) * F_PITCH + x + 3 + shift];
+    const bool mine = incol && ((cellmask >> cj) & 1u);
+    // ---- V map for the masked cells.  Each wavefront works on its own 64 columns in
+    // bands of F_QROWS rows: quick reject -> compaction into the wave's queue -> full
+    // test on the survivors -> corners appended to the wave's corner list.  No workgroup
+    // barrier inside: the queues are private to the wave and LDS operations of one wave
+    // complete in order.
+    if (__ballot(mine)) {
+      for (int y0 = 0; y0 < hi; y0 += F_QROWS) {
+        const int y1 = min(y0 + F_QROWS, hi);
+        int wcount = 0;  // wave-uniform
+        for (int y = y0; y < y1; y++) {
+          const uint8_t* p = &s_img[(y + 3) * F_PITCH + colo];
           const int c = p[0];
-          const int p0 = p[3 * F_PITCH], p4 = p[3], p8 = p[-3 * F_PITCH], p12 = p[-3];
-          const int hi_t = c + t, lo_t = c - t;
-          const bool b0 = p0 > hi_t, b4 = p4 > hi_t, b8 = p8 > hi_t, b12 = p12 > hi_t;
-          const bool d0 = p0 < lo_t, d4 = p4 < lo_t, d8 = p8 < lo_t, d12 = p12 < lo_t;
-          // any 9 contiguous ring pixels contain two adjacent compass points
-          ok = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (d0 & d4) | (d4 & d8) | (d8 & d12) | (d12 & d0);
+          const int e0 = (int)p[3 * F_PITCH] - c, e4 = (int)p[3] - c, e8 = (int)p[-3 * F_PITCH] - c, e12 = (int)p[-3] - c;
+          // sign bit of (t - e) <=> brighter by more than t; of (t + e) <=> darker.  Nine
+          // contiguous ring pixels always contain two adjacent compass points:
+          // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12)
+          const int br = ((t - e0) | (t - e8)) & ((t - e4) | (t - e12));
+          const int dk = ((t + e0) | (t + e8)) & ((t + e4) | (t + e12));
+          const bool ok = mine && ((br | dk) < 0);
+          const unsigned long long m = __ballot(ok);
+          if (ok) s_list[wave][wcount + __popcll(m & lt_mask)] = (uint16_t)(((y - y0) << 8) | x);
+          wcount += __popcll(m);
         }
-        if (ok) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(i - band);
+        for (int k0 = 0; k0 < wcount; k0 += 64) {
+          const int k = k0 + lane;
+          bool corner = false;
+          int e = 0;
+          if (k < wcount) {
+            e = s_list[wave][k];
+            const int off = ((e >> 8) + y0 + 3) * F_PITCH + (e & 0xFF) + 3 + shift;
+            const int v = fast_v(&s_img[off]);
+            corner = v > t;
+            s_v[off] = (uint8_t)(corner ? v : 0);
+          }
+          const unsigned long long m = __ballot(corner);
+          const int nc = __popcll(m);
+          if (ncorner + nc > F_CCAP) overflow = true;
+          else if (corner) s_corner[wave][ncorner + __popcll(m & lt_mask)] = (uint16_t)(e + (y0 << 8));
+          if (!overflow) ncorner += nc;
+        }
       }
-      __syncthreads();
-      const int nl = s_nlist;
-      for (int k = tid; k < nl; k += F_THREADS) {
-        const int i = band + s_list[k];
-        const int y = i / wi, x = i - y * wi;
-        const int off = (y + 3) * F_PITCH + x + 3 + shift;
-        const int v = fast_v(&s_img[off]);
-        s_v[off] = (uint8_t)(v > t ? v : 0);
-      }
-      __syncthreads();
     }
-    // ---- cell-local NMS: count per cell
-    for (int i = tid; i < npix; i += F_THREADS) {
-      const int y = i / wi, x = i - y * wi;
-      const int cj = x / wCell;
-      if (!((cellmask >> cj) & 1u)) continue;
-      const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + 3 + shift];
-      const int v = q[0];
-      if (v < 2) continue;
+    if (lane == 0) s_ncorner[wave] = overflow ? -1 : ncorner;
+    __syncthreads();
+    // ---- cell-local NMS, count per cell: over the corner lists (or densely on overflow)
+    const bool any_overflow = s_ncorner[0] < 0 || s_ncorner[1] < 0 || s_ncorner[2] < 0 || s_ncorner[3] < 0;
+    if (!any_overflow) {
+      for (int k = lane; k < ncorner; k += 64) {
+        const int e = s_corner[wave][k];
+        const int ex = e & 0xFF, ey = e >> 8;
+        const int ecj = ex / wCell, exc = ex - ecj * wCell;
+        if (!((cellmask >> ecj) & 1u)) continue;
+        const uint8_t* q = &s_v[(ey + 3) * F_PITCH + ex + 3 + shift];
+        const int v = q[0];
+        if (v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1)) atomicAdd(&s_cnt[ecj], 1);
+      }
+    } else if (mine) {
       const int xc = x - cj * wCell;
-      const bool hasL = xc > 0, hasR = (xc < wCell - 1);
-      bool keep = v > q[-F_PITCH] && v > q[F_PITCH];
-      if (hasL) keep = keep && v > q[-1] && v > q[-F_PITCH - 1] && v > q[F_PITCH - 1];
-      if (hasR) keep = keep && v > q[1] && v > q[-F_PITCH + 1] && v > q[F_PITCH + 1];
-      if (keep) atomicAdd(&s_cnt[cj], 1);
+      int n = 0;
+      for (int y = 0; y < hi; y++) {
+        const uint8_t* q = &s_v[(y + 3) * F_PITCH + colo];
+        const int v = q[0];
+        if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) n++;
+      }
+      if (n) atomicAdd(&s_cnt[cj], n);
     }
     __syncthreads();
     if (pass == 1) break;
@@ -311,10 +355,21 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       if (s_cnt[c] == 0) need |= 1u << c;
     if (need == 0) break;  // uniform
     cellmask = need;
-    // clear the V columns of the cells that get the lower threshold
-    for (int i = tid; i < npix; i += F_THREADS) {
-      const int y = i / wi, x = i - y * wi;
-      if ((need >> (x / wCell)) & 1u) s_v[(y + 3) * F_PITCH + x + 3 + shift] = 0;
+    // the cells that get the lower threshold start over: clear their V columns and drop
+    // their corners from the lists
+    if (incol && ((need >> cj) & 1u))
+      for (int y = 0; y < hi; y++) s_v[(y + 3) * F_PITCH + colo] = 0;
+    if (!overflow) {
+      int kept = 0;
+      for (int k0 = 0; k0 < ncorner; k0 += 64) {
+        const int k = k0 + lane;
+        const int e = k < ncorner ? (int)s_corner[wave][k] : 0;
+        const bool keep = k < ncorner && !((need >> ((e & 0xFF) / wCell)) & 1u);
+        const unsigned long long m = __ballot(keep);
+        if (keep) s_corner[wave][kept + __popcll(m & lt_mask)] = (uint16_t)e;
+        kept += __popcll(m);
+      }
+      ncorner = kept;
     }
     __syncthreads();
   }
@@ -331,21 +386,30 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   if (s_total == 0) return;
   uint32_t* out = cand_all + (size_t)f * P.cand_total + L.cand_off;
   const int gbase = s_base;
-  for (int i = tid; i < npix; i += F_THREADS) {
-    const int y = i / wi, x = i - y * wi;
-    const int cj = x / wCell;
-    const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + 3 + shift];
-    const int v = q[0];
-    if (v < 2) continue;
+  const bool any_overflow = s_ncorner[0] < 0 || s_ncorner[1] < 0 || s_ncorner[2] < 0 || s_ncorner[3] < 0;
+  if (!any_overflow) {
+    for (int k = lane; k < ncorner; k += 64) {
+      const int e = s_corner[wave][k];
+      const int ex = e & 0xFF, ey = e >> 8;
+      const int ecj = ex / wCell, exc = ex - ecj * wCell;
+      const uint8_t* q = &s_v[(ey + 3) * F_PITCH + ex + 3 + shift];
+      const int v = q[0];
+      if (v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1)) {
+        const int slot = gbase + atomicAdd(&s_emit, 1);
+        const int xr = xb + 3 + ex - kBorder, yr = iniY + 3 + ey - kBorder;
+        if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
+      }
+    }
+  } else if (incol) {
     const int xc = x - cj * wCell;
-    const bool hasL = xc > 0, hasR = (xc < wCell - 1);
-    bool keep = v > q[-F_PITCH] && v > q[F_PITCH];
-    if (hasL) keep = keep && v > q[-1] && v > q[-F_PITCH - 1] && v > q[F_PITCH - 1];
-    if (hasR) keep = keep && v > q[1] && v > q[-F_PITCH + 1] && v > q[F_PITCH + 1];
-    if (keep) {
-      const int slot = gbase + atomicAdd(&s_emit, 1);
-      const int xr = xb + 3 + x - kBorder, yr = iniY + 3 + y - kBorder;
-      if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
+    for (int y = 0; y < hi; y++) {
+      const uint8_t* q = &s_v[(y + 3) * F_PITCH + colo];
+      const int v = q[0];
+      if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) {
+        const int slot = gbase + atomicAdd(&s_emit, 1);
+        const int xr = xb + 3 + x - kBorder, yr = iniY + 3 + y - kBorder;
+        if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
+      }
     }
   }
 }
