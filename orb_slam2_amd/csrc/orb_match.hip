@@ -140,11 +140,12 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, co
 // Greedy matchers
 // ---------------------------------------------------------------------------
 constexpr int MK = 4;  // ranked candidates kept per query
-constexpr int M_THREADS = 256;
+constexpr int M_THREADS = 1024;
 enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2 };
 
 struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
+  int lists_in_lds;  // the ranked candidate lists of all queries fit in LDS next to the grid
   int ts, qs;  // element stride (4-byte units) of t_x/t_y/t_oct/t_angle and of q_oct/q_angle:
                // 1 for separate arrays, 6 for fields of OrbKeyPoint records
   const int* n_q; const int* n_t;
@@ -194,6 +195,9 @@ struct MatchShared {
   float* kx; float* ky;  // max_t
   unsigned char* koct;   // max_t
   unsigned char* occ;    // max_t: train keypoint can no longer be taken
+  int* claim;            // max_t: lowest pending lane that wants to take the keypoint
+  uint2* lists;          // max_q * MK ranked candidates (LDS if it fits, else global scratch)
+  int* ntot;             // max_q: candidates seen (bit 30: the query's map point has observations), -1 = inactive
 };
 
 // Frame::GetFeaturesInArea (reference src/Frame.cc:371-449) fused with the best /
@@ -287,7 +291,16 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     S.ky = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
     S.items = reinterpret_cast<unsigned short*>(p); p += sizeof(unsigned short) * ((A.max_t + 1) & ~1);
     S.koct = p; p += (A.max_t + 3) & ~3;
-    S.occ = p;
+    S.occ = p; p += (A.max_t + 3) & ~3;
+    S.claim = reinterpret_cast<int*>(p); p += sizeof(int) * A.max_t;
+    p = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
+    if (A.lists_in_lds) {
+      S.lists = reinterpret_cast<uint2*>(p); p += sizeof(uint2) * MK * A.max_q;
+      S.ntot = reinterpret_cast<int*>(p);
+    } else {
+      S.lists = A.lists + (size_t)pair * A.max_q * MK;
+      S.ntot = A.q_ntot + (size_t)pair * A.max_q;
+    }
   }
   const size_t tbase = (size_t)pair * A.max_t, qbase = (size_t)pair * A.max_q;
   int* out_match = A.out_match + (MODE == MODE_TRIANG ? qbase : tbase);
@@ -298,6 +311,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     S.kx[j] = A.t_x[(tbase + j) * A.ts]; S.ky[j] = A.t_y[(tbase + j) * A.ts];
     S.koct[j] = (unsigned char)min(max(A.t_oct[(tbase + j) * A.ts], 0), 255);
     S.occ[j] = (unsigned char)(A.t_obs[tbase + j] > 0);
+    S.claim[j] = 0x7FFFFFFF;
     if (MODE != MODE_TRIANG) out_match[j] = -1;
   }
   if (MODE == MODE_TRIANG)
@@ -396,11 +410,12 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       scan_query<MODE>(A, S, pair, nt, geo, qd, b0, b1, qx, qy, c);
     }
     A.q_geo[qbase + i] = geo;
-    A.q_ntot[qbase + i] = valid ? c.ntot : -1;
+    int obs_bit = 0;
+    if (MODE != MODE_TRIANG) obs_bit = A.q_obs[qbase + i] > 0 ? 0x40000000 : 0;
+    S.ntot[i] = valid ? (c.ntot | obs_bit) : -1;
 #pragma unroll
-    for (int k = 0; k < MK; k++) A.lists[(qbase + i) * MK + k] = make_uint2(c.key[k], c.idx[k]);
+    for (int k = 0; k < MK; k++) S.lists[i * MK + k] = make_uint2(c.key[k], c.idx[k]);
     A.q_slot[qbase + i] = -1;
-    A.q_bin[qbase + i] = -1;
   }
   __syncthreads();
 
@@ -409,13 +424,17 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     const int lane = tid;
     for (int base = 0; base < nq; base += 64) {
       const int i = base + lane;
-      const bool active = i < nq && A.q_ntot[qbase + min(i, nq - 1)] > 0;
+      const int nt_i = i < nq ? S.ntot[i] : -1;
+      const bool active = nt_i > 0 && (nt_i & 0x3FFFFFFF) > 0;
+      const bool q_occupies = (nt_i & 0x40000000) != 0;
       Cand c;
       cand_init(c);
+      int my_idx1 = 0;
       if (active) {
 #pragma unroll
-        for (int k = 0; k < MK; k++) { const uint2 e = A.lists[(qbase + i) * MK + k]; c.key[k] = e.x; c.idx[k] = e.y; }
-        c.ntot = A.q_ntot[qbase + i];
+        for (int k = 0; k < MK; k++) { const uint2 e = S.lists[i * MK + k]; c.key[k] = e.x; c.idx[k] = e.y; }
+        c.ntot = nt_i & 0x3FFFFFFF;
+        if (MODE == MODE_TRIANG) my_idx1 = A.q_idx1[qbase + i];
       }
       bool resolved = !active;
       while (true) {
@@ -461,28 +480,32 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
         if (!resolved && s1 >= 0) {
           if constexpr (MODE == MODE_FRAMES) {
             accept = d1 <= TH_HIGH;
-            occupy = accept && A.q_obs[qbase + i] > 0;
+            occupy = accept && q_occupies;
           } else if constexpr (MODE == MODE_MAPPOINTS) {
             accept = d1 <= TH_HIGH;
             if (accept) {
               const int l1 = S.koct[s1], l2 = s2 >= 0 ? (int)S.koct[s2] : -1;
               if (l1 == l2 && (float)d1 > A.nnratio * (float)d2) accept = false;
             }
-            occupy = accept && A.q_obs[qbase + i] > 0;
+            occupy = accept && q_occupies;
           } else {
             accept = true;  // thresholds were applied during the scan
             occupy = true;
           }
         }
         // does an earlier unresolved query of this step take a slot this one looks at?
-        bool conflict = false;
         const unsigned long long pending = __ballot(!resolved);
         if (pending == 0) break;
-        for (int o = 0; o < 64; o++) {
-          if (!((pending >> o) & 1ull)) continue;  // uniform
-          const int os = __shfl(occupy ? s1 : -1, o);
-          if (o < lane && !resolved && os >= 0 && (os == s1 || (MODE == MODE_MAPPOINTS && os == s2))) conflict = true;
+        // claim[s] = lowest pending lane that would occupy s
+        if (occupy) atomicMin(&S.claim[s1], lane);
+        __builtin_amdgcn_wave_barrier();
+        bool conflict = false;
+        if (!resolved && s1 >= 0) {
+          conflict = S.claim[s1] < lane;
+          if (MODE == MODE_MAPPOINTS && s2 >= 0) conflict = conflict || S.claim[s2] < lane;
         }
+        __builtin_amdgcn_wave_barrier();
+        if (occupy) S.claim[s1] = 0x7FFFFFFF;
         const unsigned long long cm = __ballot(conflict);
         const int first_conf = cm ? (__ffsll((long long)cm) - 1) : 64;
         if (!resolved && lane < first_conf) {
@@ -490,17 +513,9 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
           if (accept) {
             if (occupy) S.occ[s1] = 1;
             atomicAdd(&s_nm, 1);
-            if constexpr (MODE == MODE_TRIANG) {
-              const int idx1 = A.q_idx1[qbase + i];
-              out_match[idx1] = s1;
-              A.q_slot[qbase + i] = idx1;
-              if (A.check_ori) A.q_bin[qbase + i] = rot_bin(A.q_angle[qbase + idx1] - A.t_angle[(tbase + s1) * A.ts]);
-            } else {
-              atomicMax(&out_match[s1], i);  // a later query overwrites an earlier one
-              A.q_slot[qbase + i] = s1;
-              if (MODE == MODE_FRAMES && A.check_ori)
-                A.q_bin[qbase + i] = rot_bin(A.q_angle[(qbase + i) * A.qs] - A.t_angle[(tbase + s1) * A.ts]);
-            }
+            A.q_slot[qbase + i] = s1;
+            if constexpr (MODE == MODE_TRIANG) out_match[my_idx1] = s1;
+            else atomicMax(&out_match[s1], i);  // a later query overwrites an earlier one
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -513,8 +528,14 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   // ComputeThreeMaxima :1943-1985)
   if (A.check_ori && MODE != MODE_MAPPOINTS) {
     for (int i = tid; i < nq; i += M_THREADS) {
-      const int b = A.q_bin[qbase + i];
-      if (b >= 0) atomicAdd(&s_hist[b], 1);
+      const int s1 = A.q_slot[qbase + i];
+      int b = -1;
+      if (s1 >= 0) {
+        const float qa = MODE == MODE_TRIANG ? A.q_angle[qbase + A.q_idx1[qbase + i]] : A.q_angle[(qbase + i) * A.qs];
+        b = rot_bin(qa - A.t_angle[(tbase + s1) * A.ts]);
+        atomicAdd(&s_hist[b], 1);
+      }
+      A.q_bin[qbase + i] = b;
     }
     __syncthreads();
     if (tid == 0) {
@@ -533,7 +554,8 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     for (int i = tid; i < nq; i += M_THREADS) {
       const int b = A.q_bin[qbase + i];
       if (b >= 0 && b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) {
-        out_match[A.q_slot[qbase + i]] = MODE == MODE_TRIANG ? -1 : -2;
+        if (MODE == MODE_TRIANG) out_match[A.q_idx1[qbase + i]] = -1;
+        else out_match[A.q_slot[qbase + i]] = -2;
         atomicSub(&s_nm, 1);
       }
     }
@@ -542,9 +564,12 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   if (tid == 0) A.n_matches[pair] = s_nm;
 }
 
-size_t match_lds_bytes(int max_t) {
-  return sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + 2 * sizeof(float) * (size_t)max_t +
-         sizeof(unsigned short) * (size_t)((max_t + 1) & ~1) + (size_t)((max_t + 3) & ~3) + (size_t)max_t + 16;
+size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds) {
+  size_t n = sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + 2 * sizeof(float) * (size_t)max_t +
+             sizeof(unsigned short) * (size_t)((max_t + 1) & ~1) + 2 * (size_t)((max_t + 3) & ~3) +
+             sizeof(int) * (size_t)max_t + 32;
+  if (lists_in_lds) n += (sizeof(uint2) * MK + sizeof(int)) * (size_t)max_q;
+  return n;
 }
 
 // ---- host helpers -------------------------------------------------------------
@@ -592,12 +617,18 @@ void carve_scratch(MatchArgs& A, void* scratch, size_t nq) {
 }
 
 template <int MODE>
-int launch_match(const MatchArgs& A, int n_pairs, hipStream_t st) {
-  const size_t lds = match_lds_bytes(A.max_t);
-  if (lds > 150 * 1024) { set_error("too many train keypoints for the LDS-resident grid (limit about 11000)"); return ORBHIP_ERR_UNSUPPORTED; }
-  if (lds > 64 * 1024)
+int launch_match(const MatchArgs& A0, int n_pairs, hipStream_t st) {
+  MatchArgs A = A0;
+  constexpr size_t kLdsLimit = 156 * 1024;
+  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true) <= kLdsLimit;
+  const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0);
+  if (lds > kLdsLimit) { set_error("too many train keypoints for the LDS-resident grid (limit about 9000)"); return ORBHIP_ERR_UNSUPPORTED; }
+  static bool raised = false;  // the attribute belongs to the function: raise it once to the limit
+  if (!raised) {
     ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_kernel<MODE>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    raised = true;
+  }
   hipLaunchKernelGGL(match_kernel<MODE>, dim3(n_pairs), dim3(M_THREADS), lds, st, A);
   ORB_HIP_CHECK(hipGetLastError());
   return ORBHIP_OK;
