@@ -746,6 +746,8 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 constexpr int D_THREADS = 256;
+constexpr int D_RAW_ROWS = 31, D_RAW_PITCH = 36;  // 31 px + up to 3 bytes of alignment
+constexpr int D_BLR_ROWS = 37, D_BLR_PITCH = 40;  // 37 px + up to 3 bytes of alignment
 
 __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* __restrict__ pyr,
                                                                 const uint8_t* __restrict__ blur,
@@ -754,6 +756,7 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
                                                                 OrbKeyPoint* __restrict__ out_kps,
                                                                 uint8_t* __restrict__ out_desc,
                                                                 int* __restrict__ n_out, int max_kp) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[D_THREADS / 64][D_RAW_ROWS * D_RAW_PITCH + D_BLR_ROWS * D_BLR_PITCH];
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * (D_THREADS / 64) + (threadIdx.x >> 6);  // slot in the per-frame selected array
@@ -775,23 +778,58 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   const int cx = (int)(v & kCoordMask) + kBorder, cy = (int)((v >> kCoordBits) & kCoordMask) + kBorder;
   const size_t lvl = (size_t)f * P.slab + L.off + (size_t)(cy + kEdge) * L.pitch + cx + kXOff;
 
+  // pattern pairs of this lane (pair = lane + 64*j): issued early, used after the angle
+  uint32_t pat[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) pat[j] = reinterpret_cast<const uint32_t*>(c_pattern)[lane + 64 * j];
+
+  // Stage the two patches of this keypoint in the wave's LDS region with aligned dword
+  // loads: rows -15..15 of the level (orientation disc) and rows -18..18 of the blurred
+  // level (a rotated pattern point reaches at most round(13*sqrt(2)) = 18 px).
+  uint8_t* s_raw = s_patch[threadIdx.x >> 6];
+  uint8_t* s_blr = s_raw + D_RAW_ROWS * D_RAW_PITCH;
+  const int al = (cx + kXOff - 15) & 3, al2 = (cx + kXOff - 18) & 3;
+  {
+    const uint8_t* g = pyr + lvl - 15 - al;  // dword aligned: pitch and offsets are multiples of 4
+#pragma unroll
+    for (int it = 0; it < (D_RAW_ROWS * 9 + 63) / 64; it++) {
+      const int i = it * 64 + lane;
+      if (i < D_RAW_ROWS * 9) {
+        const int r = i / 9, c = i - r * 9;
+        *reinterpret_cast<uint32_t*>(&s_raw[r * D_RAW_PITCH + 4 * c]) =
+            *reinterpret_cast<const uint32_t*>(g + (ptrdiff_t)(r - 15) * L.pitch + 4 * c);
+      }
+    }
+    const uint8_t* gb = blur + lvl - 18 - al2;
+#pragma unroll
+    for (int it = 0; it < (D_BLR_ROWS * 10 + 63) / 64; it++) {
+      const int i = it * 64 + lane;
+      if (i < D_BLR_ROWS * 10) {
+        const int r = i / 10, c = i - r * 10;
+        *reinterpret_cast<uint32_t*>(&s_blr[r * D_BLR_PITCH + 4 * c]) =
+            *reinterpret_cast<const uint32_t*>(gb + (ptrdiff_t)(r - 18) * L.pitch + 4 * c);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
   // intensity centroid: lane = 2*row + half
   int m10 = 0, m01 = 0;
   {
-    const int row = lane >> 1, half = lane & 1;
-    if (row < 31) {
-      const int vv = row - 15;
-      const int d = c_umax[vv < 0 ? -vv : vv];
-      const uint8_t* p = pyr + lvl + (ptrdiff_t)vv * L.pitch;
-      int sum = 0;
-      const int u0 = half ? 0 : -d, u1 = half ? d : -1;
-      for (int u = u0; u <= u1; u++) {
-        const int val = p[u];
-        m10 += u * val;
-        sum += val;
-      }
-      m01 = vv * sum;
+    const int row = min(lane >> 1, 30), half = lane & 1;
+    const int vv = row - 15;
+    const int d = c_umax[vv < 0 ? -vv : vv];
+    const uint8_t* p = &s_raw[row * D_RAW_PITCH + 15 + al];
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int u = half ? j : -1 - j;
+      const int au = half ? j : j + 1;
+      const int x = (au <= d && lane < 62) ? (int)p[u] : 0;
+      m10 += u * x;
+      sum += x;
     }
+    m01 = vv * sum;
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
@@ -800,25 +838,26 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-  // steered BRIEF on the blurred level
+  // steered BRIEF on the blurred patch
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float rad = __fmul_rn(angle, factorPI);
   const float a = (float)cos((double)rad), b = (float)sin((double)rad);
-  const uint8_t* ctr = blur + lvl;
-  const int pitch = L.pitch;
-  unsigned long long bits[4];
+  const uint8_t* ctr = &s_blr[18 * D_BLR_PITCH + 18 + al2];
+  int t0[4], t1[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int pr = lane + 64 * j;
-    const int px0 = c_pattern[4 * pr], py0 = c_pattern[4 * pr + 1];
-    const int px1 = c_pattern[4 * pr + 2], py1 = c_pattern[4 * pr + 3];
+    const int px0 = (int)(int8_t)(pat[j] & 0xFF), py0 = (int)(int8_t)((pat[j] >> 8) & 0xFF);
+    const int px1 = (int)(int8_t)((pat[j] >> 16) & 0xFF), py1 = (int)(int8_t)(pat[j] >> 24);
     const int r0 = __float2int_rn(__fadd_rn(__fmul_rn((float)px0, b), __fmul_rn((float)py0, a)));
     const int q0 = __float2int_rn(__fsub_rn(__fmul_rn((float)px0, a), __fmul_rn((float)py0, b)));
     const int r1 = __float2int_rn(__fadd_rn(__fmul_rn((float)px1, b), __fmul_rn((float)py1, a)));
     const int q1 = __float2int_rn(__fsub_rn(__fmul_rn((float)px1, a), __fmul_rn((float)py1, b)));
-    const int t0 = ctr[(ptrdiff_t)r0 * pitch + q0], t1 = ctr[(ptrdiff_t)r1 * pitch + q1];
-    bits[j] = __ballot(t0 < t1);
+    t0[j] = ctr[r0 * D_BLR_PITCH + q0];
+    t1[j] = ctr[r1 * D_BLR_PITCH + q1];
   }
+  unsigned long long bits[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) bits[j] = __ballot(t0[j] < t1[j]);
   if (lane < 4) {
     const unsigned long long w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
     reinterpret_cast<unsigned long long*>(out_desc + ((size_t)f * max_kp + o) * 32)[lane] = w;

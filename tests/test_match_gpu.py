@@ -193,3 +193,55 @@ def test_search_for_triangulation(oracle, seed, n1, n2, ori):
         flat(kf1.mFeatVec), flat(kf2.mFeatVec), F12, (ex, ey), sf, s2, ori)
     assert got_n == want_n and want_n > 20
     assert pairs == [(i, int(want_m[i])) for i in range(n1) if want_m[i] >= 0]
+
+
+def test_projection_many_queries_one_spot(oracle):
+    """Forty map points with the same descriptor project onto one crowded spot and each
+    occupies what it takes: every query has to skip what the earlier ones took, far beyond
+    the few candidates a query keeps from its first scan."""
+    from orb_slam2_amd import Frame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(77)
+    sf, s2 = scale_tables()
+    nc, nl = 300, 40
+    cx_, cy_, coct, cang, cdesc = random_frame_arrays(rng, nc, 376, 1241)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    crowd = np.arange(60)
+    cx_[crowd] = 600 + rng.uniform(-5, 5, 60).astype(np.float32)
+    cy_[crowd] = 200 + rng.uniform(-5, 5, 60).astype(np.float32)
+    coct[crowd] = 2
+    cdesc[crowd] = flip_bits(rng, np.repeat(base[None], 60, 0), 30)
+    K = (np.float32(700), np.float32(700), np.float32(620.5), np.float32(188))
+    Xw = np.tile(np.array([[(600 - 620.5) / 700 * 10, (200 - 188) / 700 * 10, 10]], np.float32), (nl, 1))
+    last = dict(mp_obs=np.full(nl, 2, np.int32), xw=Xw, mp_desc=np.repeat(base[None], nl, 0),
+                octave=np.full(nl, 2, np.int32), angle=rng.uniform(0, 360, nl).astype(np.float32))
+    cur = dict(x=cx_, y=cy_, octave=coct, angle=cang, desc=cdesc, obs=np.full(nc, -1, np.int32))
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    want_n, want_m = oracle.search_by_projection_frames(np.eye(4, dtype=np.float32), K, bounds, sf, last, cur, 7.0, False)
+    assert want_n == nl and len(set(want_m[want_m >= 0].tolist())) == nl  # forty distinct slots
+    lf = Frame(kp_struct(np.zeros(nl), np.zeros(nl), last["octave"], last["angle"]), np.zeros((nl, 32), np.uint8), sf, s2, K, bounds)
+    for i in range(nl):
+        lf.mvpMapPoints[i] = MapPoint(Xw[i], base, 2)
+    cf = Frame(kp_struct(cx_, cy_, coct, cang), cdesc, sf, s2, K, bounds)
+    nm, match = ORBmatcher(0.9, False).search_by_projection_frames_batch([cf], [lf], 7.0)
+    assert nm[0] == want_n and np.array_equal(match[0, :nc], want_m)
+
+
+def test_knn2_merge_of_shards(oracle):
+    """Three database shards searched separately on one GPU and merged equal one scan."""
+    import torch
+    from orb_slam2_amd.dist import hip_local_search, hip_merge, shard_bounds
+    from orb_slam2_amd.synth import synth_descriptors
+    db, q = synth_descriptors(5000, 1500, seed=9)
+    db[3000] = db[10]; db[4000] = db[10]
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(q).to(dev)
+    parts = []
+    for r in range(3):
+        lo, hi = shard_bounds(len(db), 3, r)
+        parts.append(hip_local_search(d_q, torch.from_numpy(db[lo:hi]).to(dev), lo, 0.7, 0)().clone())
+    g = torch.stack(parts, 1).contiguous()  # [3][shards][nq]
+    out, acc = hip_merge(0.7, 0)(g)
+    torch.cuda.synchronize()
+    rb, rs, ri, ra = oracle.knn2_bruteforce(q, db, 0.7)
+    assert np.array_equal(out[0].cpu().numpy(), rb) and np.array_equal(out[1].cpu().numpy(), rs)
+    assert np.array_equal(out[2].cpu().numpy(), ri) and np.array_equal(acc.cpu().numpy(), ra)
