@@ -656,66 +656,79 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
 // (acc + 2^15) >> 16.  The padded pyramid already holds the reflected border.
 // ---------------------------------------------------------------------------
 constexpr int B_TW = 128, B_TH = 32, B_THREADS = 256;
-constexpr int B_INP = B_TW + 16;  // staged row bytes (tile + 8, rounded up)
+constexpr int B_ROWS = B_TH + 6;  // staged rows: 3 above, 3 below
+constexpr int B_INP = 160;        // staged bytes per row: level x0-16 .. x0+143
 
+typedef unsigned short blur_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t blur_dot2(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, a), __builtin_bit_cast(blur_us2, b), c, false);
+}
+
+// Row pass with v_dot4_u32_u8 (taps are bytes), two image rows per thread so that the
+// 8.8 results of vertically adjacent rows share a dword; column pass with
+// v_dot2_u32_u16 on those row pairs.
 __global__ __launch_bounds__(B_THREADS) void blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                                          Plan P, const BlurItem* __restrict__ items, int t0, int t1,
                                                          int t2, int t3) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_in[(B_TH + 6) * B_INP];
-  __shared__ __attribute__((aligned(16))) uint16_t s_h[(B_TH + 6) * B_TW];
+  __shared__ __attribute__((aligned(16))) uint8_t s_in[B_ROWS * B_INP];
+  __shared__ __attribute__((aligned(16))) uint32_t s_hp[(B_ROWS / 2) * B_TW];  // h[2p][x] | h[2p+1][x] << 16
   const BlurItem it = items[blockIdx.x];
   const int f = blockIdx.y, tid = threadIdx.x;
   const LevelGeom& L = P.lv[it.level];
   const int x0 = it.tx * B_TW, y0 = it.ty * B_TH;
   const int tw = min(B_TW, L.w - x0), th = min(B_TH, L.h - y0);
   const int tw4 = (tw + 3) >> 2;
-  // staged columns: level x in [x0 - 4, x0 - 4 + 4*ndw)
-  const int ndw = tw4 + 2;
-  const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(y0 - 3 + kEdge) * L.pitch + (x0 - 4 + kXOff);
-  for (int i = tid; i < (th + 6) * ndw; i += B_THREADS) {
-    const int r = i / ndw, c = i - r * ndw;
-    *reinterpret_cast<uint32_t*>(&s_in[r * B_INP + 4 * c]) =
-        *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * c);
+  const int n16 = (4 * tw4 + 24 + 15) >> 4;  // 16-byte pieces per staged row
+  const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(y0 - 3 + kEdge) * L.pitch + (x0 - 16 + kXOff);
+  for (int i = tid; i < (th + 6) * 10; i += B_THREADS) {
+    const int r = i / 10, c = i - r * 10;
+    if (c < n16)
+      *reinterpret_cast<uint4*>(&s_in[r * B_INP + 16 * c]) =
+          *reinterpret_cast<const uint4*>(base + (size_t)r * L.pitch + 16 * c);
   }
   __syncthreads();
-  for (int i = tid; i < (th + 6) * tw4; i += B_THREADS) {
-    const int r = i / tw4, c = i - r * tw4;
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_in[r * B_INP + 4 * c]);
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-    int b[12];
+  const uint32_t T1 = (uint32_t)t0 | ((uint32_t)t1 << 8) | ((uint32_t)t2 << 16) | ((uint32_t)t3 << 24);
+  const uint32_t T2 = (uint32_t)t2 | ((uint32_t)t1 << 8) | ((uint32_t)t0 << 16);
+  const int c = tid & 31, rsub = tid >> 5;
+  if (c < tw4) {
+    for (int pr = rsub; pr < (th + 6 + 1) / 2; pr += B_THREADS / 32) {
+      uint32_t h[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      b[k] = (w0 >> (8 * k)) & 0xFF;
-      b[4 + k] = (w1 >> (8 * k)) & 0xFF;
-      b[8 + k] = (w2 >> (8 * k)) & 0xFF;
+      for (int k = 0; k < 2; k++) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_in[(2 * pr + k) * B_INP + 4 * c + 12]);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        // pixel j uses staged bytes j+1 .. j+7 of (w0, w1, w2)
+        h[k][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), T2, 0u, false), false);
+        h[k][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), T2, 0u, false), false);
+        h[k][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), T2, 0u, false), false);
+        h[k][3] = __builtin_amdgcn_udot4(w1, T1, __builtin_amdgcn_udot4(w2, T2, 0u, false), false);
+      }
+      uint4 o;
+      o.x = h[0][0] | (h[1][0] << 16); o.y = h[0][1] | (h[1][1] << 16);
+      o.z = h[0][2] | (h[1][2] << 16); o.w = h[0][3] | (h[1][3] << 16);
+      *reinterpret_cast<uint4*>(&s_hp[pr * B_TW + 4 * c]) = o;
     }
-    uint16_t h[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      h[j] = (uint16_t)(t0 * (b[j + 1] + b[j + 7]) + t1 * (b[j + 2] + b[j + 6]) + t2 * (b[j + 3] + b[j + 5]) + t3 * b[j + 4]);
-    uint2 o;
-    o.x = h[0] | ((uint32_t)h[1] << 16);
-    o.y = h[2] | ((uint32_t)h[3] << 16);
-    *reinterpret_cast<uint2*>(&s_h[r * B_TW + 4 * c]) = o;
   }
   __syncthreads();
-  uint8_t* dst = blur + (size_t)f * P.slab + L.off + (size_t)(y0 + kEdge) * L.pitch + x0 + kXOff;
-  for (int i = tid; i < th * tw4; i += B_THREADS) {
-    const int r = i / tw4, c = i - r * tw4;
-    uint32_t acc[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-      const uint2 v = *reinterpret_cast<const uint2*>(&s_h[(r + k) * B_TW + 4 * c]);
-      const int t = k == 0 || k == 6 ? t0 : (k == 1 || k == 5 ? t1 : (k == 2 || k == 4 ? t2 : t3));
-      acc[0] += t * (v.x & 0xFFFF);
-      acc[1] += t * (v.x >> 16);
-      acc[2] += t * (v.y & 0xFFFF);
-      acc[3] += t * (v.y >> 16);
-    }
-    uint32_t o = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) o |= min((acc[j] + 32768u) >> 16, 255u) << (8 * j);
-    *reinterpret_cast<uint32_t*>(dst + (size_t)r * L.pitch + 4 * c) = o;
+  if (c >= tw4) return;
+  // tap pairs for an output row whose first tap row is even / odd in the staged numbering
+  const uint32_t TPe0 = (uint32_t)t0 | ((uint32_t)t1 << 16), TPe1 = (uint32_t)t2 | ((uint32_t)t3 << 16);
+  const uint32_t TPe2 = (uint32_t)t2 | ((uint32_t)t1 << 16), TPe3 = (uint32_t)t0;
+  const uint32_t TPo0 = (uint32_t)t0 << 16, TPo1 = (uint32_t)t1 | ((uint32_t)t2 << 16);
+  const uint32_t TPo2 = (uint32_t)t3 | ((uint32_t)t2 << 16), TPo3 = (uint32_t)t1 | ((uint32_t)t0 << 16);
+  uint8_t* dst = blur + (size_t)f * P.slab + L.off + (size_t)(y0 + kEdge) * L.pitch + x0 + kXOff + 4 * c;
+  for (int y = rsub; y < th; y += B_THREADS / 32) {
+    const bool odd = y & 1;
+    const uint32_t tp0 = odd ? TPo0 : TPe0, tp1 = odd ? TPo1 : TPe1, tp2 = odd ? TPo2 : TPe2, tp3 = odd ? TPo3 : TPe3;
+    const uint4* hp = reinterpret_cast<const uint4*>(&s_hp[(y >> 1) * B_TW + 4 * c]);
+    const uint4 v0 = hp[0], v1 = hp[B_TW / 4], v2 = hp[2 * (B_TW / 4)], v3 = hp[3 * (B_TW / 4)];
+    const uint32_t a0 = blur_dot2(v3.x, tp3, blur_dot2(v2.x, tp2, blur_dot2(v1.x, tp1, blur_dot2(v0.x, tp0, 32768u))));
+    const uint32_t a1 = blur_dot2(v3.y, tp3, blur_dot2(v2.y, tp2, blur_dot2(v1.y, tp1, blur_dot2(v0.y, tp0, 32768u))));
+    const uint32_t a2 = blur_dot2(v3.z, tp3, blur_dot2(v2.z, tp2, blur_dot2(v1.z, tp1, blur_dot2(v0.z, tp0, 32768u))));
+    const uint32_t a3 = blur_dot2(v3.w, tp3, blur_dot2(v2.w, tp2, blur_dot2(v1.w, tp1, blur_dot2(v0.w, tp0, 32768u))));
+    // results are < 2^24: byte 2 of each accumulator is the output pixel
+    const uint32_t o = ((a0 >> 16) & 0xFF) | ((a1 >> 8) & 0xFF00) | (a2 & 0xFF0000) | ((a3 << 8) & 0xFF000000u);
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch) = o;
   }
 }
 
