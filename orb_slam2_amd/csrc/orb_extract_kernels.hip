@@ -170,54 +170,41 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
 // then V - 1; so one V map serves both thresholds.
 // ---------------------------------------------------------------------------
 constexpr int F_THREADS = 256;
-constexpr int F_USEW = 256;   // widest run of cell interiors per workgroup
-constexpr int F_PITCH = 272;  // LDS row pitch: F_USEW + 6 halo + 3 alignment, rounded up
+constexpr int F_USEW = 240;   // widest run of cell interiors per workgroup
+constexpr int F_PITCH = 272;  // LDS row pitch; a wavefront's 64 lanes x 4 columns cover a staged row
 constexpr int F_MAXH = 66;    // tallest cell view (hCell <= 59, + 6)
 constexpr int F_MAXCELLS = 16;
-constexpr int F_QROWS = 16;           // rows per band of a wavefront's queue
-constexpr int F_QCAP = 64 * F_QROWS;  // every pixel of the band may pass the quick test
-constexpr int F_CCAP = 512;           // corners kept per wavefront before falling back to a dense sweep
+constexpr int F_QCAP = 64 + 256;  // a wave's queue: carried-over remainder + one row of survivors
+constexpr int F_CCAP = 512;       // corners kept per wavefront before falling back to a dense sweep
+static_assert(3 + F_USEW + 6 <= 256, "a staged row must fit 64 lanes x 4 columns");
 
+typedef short fast_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fast_s2 as_s2(uint32_t v) { return __builtin_bit_cast(fast_s2, v); }
+__device__ __forceinline__ uint32_t as_u32(fast_s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ fast_s2 pk_min(fast_s2 a, fast_s2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ fast_s2 pk_max(fast_s2 a, fast_s2 b) { return __builtin_elementwise_max(a, b); }
+
+// V = max(A, B) of the pixel at p (see above), on packed 16-bit lanes: every register
+// holds (d[k], -d[k]), so the sliding minima of d and of -d are computed together.
 __device__ __forceinline__ int fast_v(const uint8_t* p /* centre in LDS */) {
-  const int c = p[0];
-  int d[16];
-  d[0] = c - p[3 * F_PITCH];
-  d[1] = c - p[3 * F_PITCH + 1];
-  d[2] = c - p[2 * F_PITCH + 2];
-  d[3] = c - p[F_PITCH + 3];
-  d[4] = c - p[3];
-  d[5] = c - p[-F_PITCH + 3];
-  d[6] = c - p[-2 * F_PITCH + 2];
-  d[7] = c - p[-3 * F_PITCH + 1];
-  d[8] = c - p[-3 * F_PITCH];
-  d[9] = c - p[-3 * F_PITCH - 1];
-  d[10] = c - p[-2 * F_PITCH - 2];
-  d[11] = c - p[-F_PITCH - 3];
-  d[12] = c - p[-3];
-  d[13] = c - p[F_PITCH - 3];
-  d[14] = c - p[2 * F_PITCH - 2];
-  d[15] = c - p[3 * F_PITCH - 1];
-  int mn[16], mx[16];
+  const uint32_t c2 = (uint32_t)p[0] * 0x10001u;
+  const fast_s2 sign = {1, -1};
+  fast_s2 P[16];
+  const int offs[16] = {3 * F_PITCH,      3 * F_PITCH + 1,  2 * F_PITCH + 2,  F_PITCH + 3,
+                        3,                -F_PITCH + 3,     -2 * F_PITCH + 2, -3 * F_PITCH + 1,
+                        -3 * F_PITCH,     -3 * F_PITCH - 1, -2 * F_PITCH - 2, -F_PITCH - 3,
+                        -3,               F_PITCH - 3,      2 * F_PITCH - 2,  3 * F_PITCH - 1};
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn[k] = min(d[k], d[(k + 1) & 15]);
-    mx[k] = max(d[k], d[(k + 1) & 15]);
-  }
-  int mn4[16], mx4[16];
+  for (int k = 0; k < 16; k++) P[k] = (as_s2(c2) - as_s2((uint32_t)p[offs[k]] * 0x10001u)) * sign;
+  fast_s2 m2[16], m4[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn4[k] = min(mn[k], mn[(k + 2) & 15]);
-    mx4[k] = max(mx[k], mx[(k + 2) & 15]);
-  }
-  int a = -256, b = 256;
+  for (int k = 0; k < 16; k++) m2[k] = pk_min(P[k], P[(k + 1) & 15]);
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-    const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-    a = max(a, m9);
-    b = min(b, x9);
-  }
-  return max(a, -b);
+  for (int k = 0; k < 16; k++) m4[k] = pk_min(m2[k], m2[(k + 2) & 15]);
+  fast_s2 best = {-256, -256};
+#pragma unroll
+  for (int k = 0; k < 16; k++) best = pk_max(best, pk_min(pk_min(m4[k], m4[(k + 4) & 15]), P[(k + 8) & 15]));
+  return max((int)best.x, (int)best.y);
 }
 
 // NMS decision for the pixel whose V byte is at q: strictly greater than the 8
@@ -236,8 +223,8 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
                                                          int* __restrict__ cand_cnt, int iniTh, int minTh) {
   __shared__ __attribute__((aligned(16))) uint8_t s_img[F_MAXH * F_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t s_v[F_MAXH * F_PITCH];
-  __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];  // per wavefront: quick-test survivors of a band
-  __shared__ uint16_t s_corner[F_THREADS / 64][F_CCAP];  // per wavefront: corners (V > t) of the tile
+  __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];    // per wavefront: quick-test survivors (row << 8 | column)
+  __shared__ uint16_t s_corner[F_THREADS / 64][F_CCAP];  // per wavefront: corners (V > t) found so far
   __shared__ int s_ncorner[F_THREADS / 64];
   __shared__ int s_cnt[F_MAXCELLS];
   __shared__ int s_total, s_base, s_emit;
@@ -255,75 +242,110 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   const int wi = tw - 6, hi = th - 6;  // interior (pixels that can be corners); wi <= F_USEW
   if (wi <= 0 || hi <= 0) return;      // uniform: a view shorter than 7 rows yields nothing
 
-  // stage the view, dword-aligned on the slab: a wave per row
+  // stage the view, dword-aligned on the slab: a wave per row.  LDS column 0 is slab
+  // column a0; interior pixel x sits in LDS column x + xoff.
   const int a0 = (xb + kXOff) & ~3;
-  const int shift = (xb + kXOff) - a0;
-  const int ndw = (shift + tw + 3) >> 2;
+  const int xoff = (xb + kXOff) - a0 + 3;
+  const int ndw = (xoff + 3 + wi + 3) >> 2;
   const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(iniY + kEdge) * L.pitch + a0;
-  for (int r = wave; r < th; r += F_THREADS / 64)
-    for (int c = lane; c < ndw; c += 64) {
-      *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * c]) =
-          *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * c);
-      *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * c]) = 0;
+  for (int r = wave; r < th; r += F_THREADS / 64) {
+    const int cc = min(lane, ndw - 1);
+    *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * lane]) =
+        *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * cc);
+    *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
+    if (lane < (F_PITCH - 256) / 4) {
+      *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 256 + 4 * lane]) = 0;
+      *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 256 + 4 * lane]) = 0;
     }
+  }
   if (tid < F_MAXCELLS) s_cnt[tid] = 0;
   __syncthreads();
 
-  // a thread owns interior column x = tid
-  const int x = tid;
-  const bool incol = x < wi;
-  const int cj = incol ? x / wCell : 0;
-  const int colo = x + 3 + shift;  // LDS column of this thread's pixels
   const unsigned long long lt_mask = (1ull << lane) - 1;
+  // the lane's four LDS columns and the cells they belong to
+  int colcell[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int x = 4 * lane + j - xoff;
+    colcell[j] = (x >= 0 && x < wi) ? x / wCell : -1;
+  }
 
   unsigned cellmask = (1u << item.ncells) - 1;  // cells to (re)compute in this pass
   int ncorner = 0;                              // wave-uniform: entries in this wave's corner list
   bool overflow = false;                        // wave-uniform: corner list too small, sweep densely
   for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? iniTh : minTh;
-    const bool mine = incol && ((cellmask >> cj) & 1u);
-    // ---- V map for the masked cells.  Each wavefront works on its own 64 columns in
-    // bands of F_QROWS rows: quick reject -> compaction into the wave's queue -> full
-    // test on the survivors -> corners appended to the wave's corner list.  No workgroup
-    // barrier inside: the queues are private to the wave and LDS operations of one wave
-    // complete in order.
-    if (__ballot(mine)) {
-      for (int y0 = 0; y0 < hi; y0 += F_QROWS) {
-        const int y1 = min(y0 + F_QROWS, hi);
-        int wcount = 0;  // wave-uniform
-        for (int y = y0; y < y1; y++) {
-          const uint8_t* p = &s_img[(y + 3) * F_PITCH + colo];
-          const int c = p[0];
-          const int e0 = (int)p[3 * F_PITCH] - c, e4 = (int)p[3] - c, e8 = (int)p[-3 * F_PITCH] - c, e12 = (int)p[-3] - c;
-          // sign bit of (t - e) <=> brighter by more than t; of (t + e) <=> darker.  Nine
-          // contiguous ring pixels always contain two adjacent compass points:
-          // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12)
-          const int br = ((t - e0) | (t - e8)) & ((t - e4) | (t - e12));
-          const int dk = ((t + e0) | (t + e8)) & ((t + e4) | (t + e12));
-          const bool ok = mine && ((br | dk) < 0);
-          const unsigned long long m = __ballot(ok);
-          if (ok) s_list[wave][wcount + __popcll(m & lt_mask)] = (uint16_t)(((y - y0) << 8) | x);
-          wcount += __popcll(m);
-        }
-        for (int k0 = 0; k0 < wcount; k0 += 64) {
-          const int k = k0 + lane;
-          bool corner = false;
-          int e = 0;
-          if (k < wcount) {
-            e = s_list[wave][k];
-            const int off = ((e >> 8) + y0 + 3) * F_PITCH + (e & 0xFF) + 3 + shift;
-            const int v = fast_v(&s_img[off]);
-            corner = v > t;
-            s_v[off] = (uint8_t)(corner ? v : 0);
-          }
-          const unsigned long long m = __ballot(corner);
-          const int nc = __popcll(m);
-          if (ncorner + nc > F_CCAP) overflow = true;
-          else if (corner) s_corner[wave][ncorner + __popcll(m & lt_mask)] = (uint16_t)(e + (y0 << 8));
-          if (!overflow) ncorner += nc;
-        }
+    bool mine[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) mine[j] = colcell[j] >= 0 && ((cellmask >> colcell[j]) & 1u);
+    const fast_s2 t2 = {(short)t, (short)t};
+    int qn = 0;  // wave-uniform: entries waiting in this wave's queue
+
+    // full test of queue entries [0, n) (n <= 64 per call chunk), corners appended
+    auto drain = [&](int head, int n) {
+      const int k = head + lane;
+      bool corner = false;
+      int e = 0;
+      if (lane < n) {
+        e = s_list[wave][k];
+        const int off = ((e >> 8) + 3) * F_PITCH + (e & 0xFF);
+        const int v = fast_v(&s_img[off]);
+        corner = v > t;
+        s_v[off] = (uint8_t)(corner ? v : 0);
+      }
+      const unsigned long long m = __ballot(corner);
+      const int nc = __popcll(m);
+      if (ncorner + nc > F_CCAP) overflow = true;
+      else if (corner) s_corner[wave][ncorner + __popcll(m & lt_mask)] = (uint16_t)e;
+      if (!overflow) ncorner += nc;
+    };
+
+    // ---- V map for the masked cells.  A wavefront takes every fourth row; a lane tests
+    // four adjacent pixels on packed 16-bit lanes.  Survivors of the quick reject go to the
+    // wave's queue, which is drained 64 entries at a time (full test on all lanes); the
+    // remainder is carried to the next row.  No workgroup barrier inside: the queues are
+    // private to the wave and LDS operations of one wave complete in order.
+    for (int y = wave; y < hi; y += F_THREADS / 64) {
+      const uint8_t* rowp = &s_img[(y + 3) * F_PITCH + 4 * lane];
+      const uint32_t C = *reinterpret_cast<const uint32_t*>(rowp);
+      const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4);
+      const uint32_t R = *reinterpret_cast<const uint32_t*>(rowp + 4);
+      const uint32_t U = *reinterpret_cast<const uint32_t*>(rowp - 3 * F_PITCH);
+      const uint32_t D = *reinterpret_cast<const uint32_t*>(rowp + 3 * F_PITCH);
+      const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1);  // pixels x-3
+      const uint32_t E = __builtin_amdgcn_alignbyte(R, C, 3);   // pixels x+3
+      uint32_t okbits = 0;
+#pragma unroll
+      for (int hsel = 0; hsel < 2; hsel++) {
+        const uint32_t sel = hsel ? 0x0c030c02u : 0x0c010c00u;  // bytes (0,1) or (2,3) widened to 16 bits
+        const fast_s2 c = as_s2(__builtin_amdgcn_perm(0u, C, sel));
+        const fast_s2 e0 = as_s2(__builtin_amdgcn_perm(0u, D, sel)) - c, e8 = as_s2(__builtin_amdgcn_perm(0u, U, sel)) - c;
+        const fast_s2 e4 = as_s2(__builtin_amdgcn_perm(0u, E, sel)) - c, e12 = as_s2(__builtin_amdgcn_perm(0u, W, sel)) - c;
+        // sign bit of (t - e) <=> brighter by more than t; of (t + e) <=> darker.  Nine
+        // contiguous ring pixels always contain two adjacent compass points:
+        // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12)
+        const uint32_t br = (as_u32(t2 - e0) | as_u32(t2 - e8)) & (as_u32(t2 - e4) | as_u32(t2 - e12));
+        const uint32_t dk = (as_u32(t2 + e0) | as_u32(t2 + e8)) & (as_u32(t2 + e4) | as_u32(t2 + e12));
+        const uint32_t r = br | dk;
+        okbits |= (((r >> 15) & 1u) | ((r >> 30) & 2u)) << (2 * hsel);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool ok = mine[j] && ((okbits >> j) & 1u);
+        const unsigned long long m = __ballot(ok);
+        if (ok) s_list[wave][qn + __popcll(m & lt_mask)] = (uint16_t)((y << 8) | (4 * lane + j));
+        qn += __popcll(m);
+      }
+      if (qn >= 64) {
+        int head = 0;
+        for (; head + 64 <= qn; head += 64) drain(head, 64);
+        const int rem = qn - head;
+        const int e = lane < rem ? (int)s_list[wave][head + lane] : 0;
+        if (lane < rem) s_list[wave][lane] = (uint16_t)e;
+        qn = rem;
       }
     }
+    if (qn) drain(0, qn);
     if (lane == 0) s_ncorner[wave] = overflow ? -1 : ncorner;
     __syncthreads();
     // ---- cell-local NMS, count per cell: over the corner lists (or densely on overflow)
@@ -331,22 +353,25 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     if (!any_overflow) {
       for (int k = lane; k < ncorner; k += 64) {
         const int e = s_corner[wave][k];
-        const int ex = e & 0xFF, ey = e >> 8;
+        const int ex = (e & 0xFF) - xoff, ey = e >> 8;
         const int ecj = ex / wCell, exc = ex - ecj * wCell;
         if (!((cellmask >> ecj) & 1u)) continue;
-        const uint8_t* q = &s_v[(ey + 3) * F_PITCH + ex + 3 + shift];
+        const uint8_t* q = &s_v[(ey + 3) * F_PITCH + (e & 0xFF)];
         const int v = q[0];
         if (v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1)) atomicAdd(&s_cnt[ecj], 1);
       }
-    } else if (mine) {
-      const int xc = x - cj * wCell;
-      int n = 0;
-      for (int y = 0; y < hi; y++) {
-        const uint8_t* q = &s_v[(y + 3) * F_PITCH + colo];
-        const int v = q[0];
-        if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) n++;
+    } else {
+      const int x = tid;  // dense sweep: a thread per interior column
+      if (x < wi && ((cellmask >> (x / wCell)) & 1u)) {
+        const int cj = x / wCell, xc = x - cj * wCell;
+        int n = 0;
+        for (int y = 0; y < hi; y++) {
+          const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + xoff];
+          const int v = q[0];
+          if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) n++;
+        }
+        if (n) atomicAdd(&s_cnt[cj], n);
       }
-      if (n) atomicAdd(&s_cnt[cj], n);
     }
     __syncthreads();
     if (pass == 1) break;
@@ -357,14 +382,17 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     cellmask = need;
     // the cells that get the lower threshold start over: clear their V columns and drop
     // their corners from the lists
-    if (incol && ((need >> cj) & 1u))
-      for (int y = 0; y < hi; y++) s_v[(y + 3) * F_PITCH + colo] = 0;
+    {
+      const int x = tid;
+      if (x < wi && ((need >> (x / wCell)) & 1u))
+        for (int y = 0; y < hi; y++) s_v[(y + 3) * F_PITCH + x + xoff] = 0;
+    }
     if (!overflow) {
       int kept = 0;
       for (int k0 = 0; k0 < ncorner; k0 += 64) {
         const int k = k0 + lane;
         const int e = k < ncorner ? (int)s_corner[wave][k] : 0;
-        const bool keep = k < ncorner && !((need >> ((e & 0xFF) / wCell)) & 1u);
+        const bool keep = k < ncorner && !((need >> (((e & 0xFF) - xoff) / wCell)) & 1u);
         const unsigned long long m = __ballot(keep);
         if (keep) s_corner[wave][kept + __popcll(m & lt_mask)] = (uint16_t)e;
         kept += __popcll(m);
@@ -390,9 +418,9 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   if (!any_overflow) {
     for (int k = lane; k < ncorner; k += 64) {
       const int e = s_corner[wave][k];
-      const int ex = e & 0xFF, ey = e >> 8;
+      const int ex = (e & 0xFF) - xoff, ey = e >> 8;
       const int ecj = ex / wCell, exc = ex - ecj * wCell;
-      const uint8_t* q = &s_v[(ey + 3) * F_PITCH + ex + 3 + shift];
+      const uint8_t* q = &s_v[(ey + 3) * F_PITCH + (e & 0xFF)];
       const int v = q[0];
       if (v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1)) {
         const int slot = gbase + atomicAdd(&s_emit, 1);
@@ -400,10 +428,10 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
       }
     }
-  } else if (incol) {
-    const int xc = x - cj * wCell;
+  } else if (tid < wi) {
+    const int x = tid, cj = x / wCell, xc = x - cj * wCell;
     for (int y = 0; y < hi; y++) {
-      const uint8_t* q = &s_v[(y + 3) * F_PITCH + colo];
+      const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + xoff];
       const int v = q[0];
       if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) {
         const int slot = gbase + atomicAdd(&s_emit, 1);
