@@ -220,9 +220,12 @@ __device__ __forceinline__ bool fast_nms_keep(const uint8_t* q, int v, bool hasL
 __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
                                                          const FastItem* __restrict__ items,
                                                          uint32_t* __restrict__ cand_all,
-                                                         int* __restrict__ cand_cnt, int iniTh, int minTh) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_img[F_MAXH * F_PITCH];
-  __shared__ __attribute__((aligned(16))) uint8_t s_v[F_MAXH * F_PITCH];
+                                                         int* __restrict__ cand_cnt, int iniTh, int minTh,
+                                                         int lds_rows) {
+  // staged view and its V map: lds_rows rows each (the tallest cell view of the plan)
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  uint8_t* const s_img = s_dyn;
+  uint8_t* const s_v = s_dyn + lds_rows * F_PITCH;
   __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];    // per wavefront: quick-test survivors (row << 8 | column)
   __shared__ uint16_t s_corner[F_THREADS / 64][F_CCAP];  // per wavefront: corners (V > t) found so far
   __shared__ int s_ncorner[F_THREADS / 64];
@@ -248,14 +251,27 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   const int xoff = (xb + kXOff) - a0 + 3;
   const int ndw = (xoff + 3 + wi + 3) >> 2;
   const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(iniY + kEdge) * L.pitch + a0;
-  for (int r = wave; r < th; r += F_THREADS / 64) {
+  {
     const int cc = min(lane, ndw - 1);
-    *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * lane]) =
-        *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * cc);
-    *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
-    if (lane < (F_PITCH - 256) / 4) {
-      *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 256 + 4 * lane]) = 0;
-      *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 256 + 4 * lane]) = 0;
+    for (int r0 = wave; r0 < th; r0 += 4 * (F_THREADS / 64)) {
+      uint32_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {  // issue the loads of four rows before the first LDS write
+        const int r = min(r0 + k * (F_THREADS / 64), th - 1);
+        v[k] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * cc);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int r = r0 + k * (F_THREADS / 64);
+        if (r < th) {
+          *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * lane]) = v[k];
+          *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
+          if (lane < (F_PITCH - 256) / 4) {
+            *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 256 + 4 * lane]) = 0;
+            *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 256 + 4 * lane]) = 0;
+          }
+        }
+      }
     }
   }
   if (tid < F_MAXCELLS) s_cnt[tid] = 0;
@@ -940,8 +956,11 @@ int pyr_tile_max_src_rows() { return PR_SROWS; }
 int pyr_tile_max_src_bytes() { return PR_SPITCH; }
 void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, uint32_t* cand, int* cand_cnt,
                  int iniTh, int minTh, int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(fast_kernel, dim3(nitems, nframes), dim3(F_THREADS), 0, st, pyr, P, items, cand, cand_cnt, iniTh,
-                     minTh);
+  int rows = 7;
+  for (int l = 0; l < P.nlevels; l++) rows = max(rows, P.lv[l].hCell + 6);
+  rows = min(rows, F_MAXH);
+  hipLaunchKernelGGL(fast_kernel, dim3(nitems, nframes), dim3(F_THREADS), 2 * (size_t)rows * F_PITCH, st, pyr, P, items,
+                     cand, cand_cnt, iniTh, minTh, rows);
 }
 template <int MAXS>
 static hipError_t launch_octree_t(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel,
