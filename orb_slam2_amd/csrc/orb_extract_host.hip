@@ -20,7 +20,7 @@ void launch_blur(const uint8_t*, uint8_t*, const Plan&, const BlurItem*, int, co
 void launch_orient_desc(const uint8_t*, const uint8_t*, const uint32_t*, const int*, const Plan&, OrbKeyPoint*,
                         uint8_t*, int*, int, int, hipStream_t);
 void launch_pyr_resize_tile(uint8_t*, const Plan&, int, const uint32_t*, const YTab*, const int2*, int, const int2*, int,
-                            int, hipStream_t);
+                            int, int, int, hipStream_t);
 int pyr_tile_cols();
 int pyr_tile_rows();
 int pyr_tile_max_src_rows();
@@ -63,7 +63,7 @@ struct OrbExtractor {
   int ot_slots = 0;    // quad-tree node slots the largest level needs
   // tiled resize: per level, packed column table (one entry per slab column) and the
   // source ranges of every tile column / tile row; tile_ok[l] = the tiled kernel applies
-  struct TileInfo { bool ok = false; int xtp_off = 0, xr_off = 0, yr_off = 0, ngx = 0, ngy = 0; };
+  struct TileInfo { bool ok = false; int xtp_off = 0, xr_off = 0, yr_off = 0, ngx = 0, ngy = 0, src_rows = 0, src_pitch = 0; };
   TileInfo tile[kMaxLevels];
   uint32_t* d_xtp = nullptr;
   int2* d_ranges = nullptr;
@@ -276,9 +276,14 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
       for (int2& r : xr) {
         if (r.y < 0) { r.x = 0; r.y = 0; }
         const int a0 = (r.x + kXOff) & ~15;
-        if (r.y + kXOff - a0 + 16 > pyr_tile_max_src_bytes() || r.y + kXOff + 16 > S.pitch) ti.ok = false;
+        const int bytes = (r.y + kXOff - a0 + 16) & ~15;  // staged bytes per row (16-byte pieces)
+        ti.src_pitch = std::max(ti.src_pitch, bytes);
+        if (bytes > pyr_tile_max_src_bytes() || r.y + kXOff + 16 > S.pitch) ti.ok = false;
       }
-      for (int2& r : yr) if (r.y - r.x + 1 > pyr_tile_max_src_rows()) ti.ok = false;
+      for (int2& r : yr) {
+        ti.src_rows = std::max(ti.src_rows, r.y - r.x + 1);
+        if (r.y - r.x + 1 > pyr_tile_max_src_rows()) ti.ok = false;
+      }
       ti.xr_off = (int)ranges.size(); ranges.insert(ranges.end(), xr.begin(), xr.end());
       ti.yr_off = (int)ranges.size(); ranges.insert(ranges.end(), yr.begin(), yr.end());
       h->tile[l] = ti;
@@ -324,7 +329,7 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
     const OrbExtractor::TileInfo& ti = h->tile[l];
     if (ti.ok)
       launch_pyr_resize_tile(h->d_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off, ti.ngx,
-                             h->d_ranges + ti.yr_off, ti.ngy, nframes, st);
+                             h->d_ranges + ti.yr_off, ti.ngy, ti.src_rows, ti.src_pitch, nframes, st);
     else
       launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
   }

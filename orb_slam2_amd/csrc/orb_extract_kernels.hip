@@ -87,15 +87,16 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ p
 // column and the second tap's weight (first weight = 2048 - it; 0xFFFF marks columns
 // outside the 19-px frame, which are written as 0).
 constexpr int PR_TC = 1024, PR_TR = 16, PR_THREADS = 256;
-constexpr int PR_SROWS = 32, PR_SPITCH = 1536;
+constexpr int PR_SROWS = 32, PR_MAXPITCH = 1536;  // limits of the staged source region
 
 __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __restrict__ pyr,
                                                                      unsigned long long slab, LevelGeom Ls,
                                                                      LevelGeom Ld, const uint32_t* __restrict__ xtp,
                                                                      const YTab* __restrict__ yt,
                                                                      const int2* __restrict__ xrange,
-                                                                     const int2* __restrict__ yrange) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_src[PR_SROWS * PR_SPITCH];
+                                                                     const int2* __restrict__ yrange, int PR_SPITCH) {
+  // staged source rows: the launch sizes this to the level's widest / tallest tile
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
   const int gx = blockIdx.x, gy = blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
   const int2 X = xrange[gx], Y = yrange[gy];
   const int a0 = (X.x + kXOff) & ~15;                  // first staged slab column
@@ -946,14 +947,16 @@ void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, c
                      yt + Ld.ytab_off);
 }
 void launch_pyr_resize_tile(uint8_t* pyr, const Plan& P, int level, const uint32_t* xtp, const YTab* yt,
-                            const int2* xrange, int ngx, const int2* yrange, int ngy, int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(pyr_resize_tile_kernel, dim3(ngx, ngy, nframes), dim3(PR_THREADS), 0, st, pyr, P.slab,
-                     P.lv[level - 1], P.lv[level], xtp, yt + P.lv[level].ytab_off, xrange, yrange);
+                            const int2* xrange, int ngx, const int2* yrange, int ngy, int src_rows, int src_pitch,
+                            int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(pyr_resize_tile_kernel, dim3(ngx, ngy, nframes), dim3(PR_THREADS), (size_t)src_rows * src_pitch, st,
+                     pyr, P.slab, P.lv[level - 1], P.lv[level], xtp, yt + P.lv[level].ytab_off, xrange, yrange,
+                     src_pitch);
 }
 int pyr_tile_cols() { return PR_TC; }
 int pyr_tile_rows() { return PR_TR; }
 int pyr_tile_max_src_rows() { return PR_SROWS; }
-int pyr_tile_max_src_bytes() { return PR_SPITCH; }
+int pyr_tile_max_src_bytes() { return PR_MAXPITCH; }
 void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, uint32_t* cand, int* cand_cnt,
                  int iniTh, int minTh, int nframes, hipStream_t st) {
   int rows = 7;
