@@ -58,7 +58,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
                                                            float ratio, int* __restrict__ out_best,
                                                            int* __restrict__ out_second, int* __restrict__ out_idx,
                                                            uint8_t* __restrict__ out_accept) {
-  __shared__ uint4 s_db[2 * KNN_TILE];
+  __shared__ uint4 s_db[2 * KNN_TILE + 2];  // + one row read ahead by the software pipeline
   const int tid = threadIdx.x;
   const int q0 = (blockIdx.x * KNN_THREADS + tid) * KNN_KQ;
   uint32_t qr[KNN_KQ][8];
@@ -83,15 +83,26 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
       __syncthreads();
       for (int i = tid; i < 2 * tn; i += KNN_THREADS) s_db[i] = db[2 * (size_t)(cbase + t0) + i];
       __syncthreads();
-#pragma unroll 4
+      uint4 n0 = s_db[0], n1 = s_db[1];
       for (int j = 0; j < tn; j++) {
-        const uint4 b0 = s_db[2 * j], b1 = s_db[2 * j + 1];
+        const uint4 b0 = n0, b1 = n1;
+        n0 = s_db[2 * j + 2]; n1 = s_db[2 * j + 3];  // next row, in flight while this one is scored
         const uint32_t row = (uint32_t)(t0 + j);
+        const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int k = 0; k < KNN_KQ; k++) {
-          const uint32_t d = (uint32_t)hamming256(qr[k], b0, b1);
+          // 8 xor + 8 popcounts chained through v_bcnt's accumulator operand (the compiler
+          // would otherwise split the chain and add the pieces with extra instructions)
+          uint32_t d;
+          asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(qr[k][0] ^ bw[0]));
+#pragma unroll
+          for (int w = 1; w < 8; w++) {
+            const uint32_t x = qr[k][w] ^ bw[w];
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+          }
           const uint32_t key = (d << KNN_ROWBITS) | row;
-          k2[k] = min(k2[k], max(k1[k], key));
+          // two smallest keys: k1 <= k2 always, so the new second is the median of the three
+          asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k2[k]) : "v"(k1[k]), "v"(key));
           k1[k] = min(k1[k], key);
         }
       }
