@@ -1,7 +1,10 @@
 // HIP kernels of the ORB extractor for gfx950 (MI355X): pyramid, cell-wise FAST,
 // quad-tree keypoint distribution, 7x7 blur, orientation + rBRIEF.
 //
-// Every kernel works on a batch: blockIdx.y (or .z) is the frame.  Integer stages
+// Every kernel works on a batch.  The frame is blockIdx.x, the fastest-varying block
+// coordinate: workgroups are dealt to the 8 XCDs round-robin, so with the frame in x all
+// workgroups of one frame land on one XCD and share its L2 (halos, overlapping patches).
+//  Integer stages
 // are bit-exact restatements of the OpenCV arithmetic the reference calls; float
 // stages use _rn intrinsics so that no multiply-add is contracted.
 #include "orb_common.h"
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
                                                                      const int2* __restrict__ yrange, int PR_SPITCH) {
   // staged source rows: the launch sizes this to the level's widest / tallest tile
   extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
-  const int gx = blockIdx.x, gy = blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
+  const int gx = blockIdx.z, gy = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
   const int2 X = xrange[gx], Y = yrange[gy];
   const int a0 = (X.x + kXOff) & ~15;                  // first staged slab column
   const int n16 = (X.y + kXOff - a0 + 16) >> 4;        // 16-byte pieces per row
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   __shared__ int s_cnt[F_MAXCELLS];
   __shared__ int s_total, s_base, s_emit;
 
-  const FastItem item = items[blockIdx.x];
-  const int f = blockIdx.y;
+  const FastItem item = items[blockIdx.y];
+  const int f = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LevelGeom& L = P.lv[item.level];
   const int wCell = L.wCell, hCell = L.hCell;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
                                                             int* __restrict__ sel_cnt, Plan P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ot_smem[];
   OtShared<OT_MAXS>& S = *reinterpret_cast<OtShared<OT_MAXS>*>(ot_smem);
-  const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int l = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
   const LevelGeom& L = P.lv[l];
   const uint32_t* pts = cand_all + (size_t)f * P.cand_total + L.cand_off;
   uint32_t* pn = pnode_all + (size_t)f * P.cand_total + L.cand_off;
@@ -717,8 +720,8 @@ __global__ __launch_bounds__(B_THREADS) void blur_kernel(const uint8_t* __restri
                                                          int t2, int t3) {
   __shared__ __attribute__((aligned(16))) uint8_t s_in[B_ROWS * B_INP];
   __shared__ __attribute__((aligned(16))) uint32_t s_hp[(B_ROWS / 2) * B_TW];  // h[2p][x] | h[2p+1][x] << 16
-  const BlurItem it = items[blockIdx.x];
-  const int f = blockIdx.y, tid = threadIdx.x;
+  const BlurItem it = items[blockIdx.y];
+  const int f = blockIdx.x, tid = threadIdx.x;
   const LevelGeom& L = P.lv[it.level];
   const int x0 = it.tx * B_TW, y0 = it.ty * B_TH;
   const int tw = min(B_TW, L.w - x0), th = min(B_TH, L.h - y0);
@@ -815,9 +818,9 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
                                                                 uint8_t* __restrict__ out_desc,
                                                                 int* __restrict__ n_out, int max_kp) {
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[D_THREADS / 64][D_RAW_ROWS * D_RAW_PITCH + D_BLR_ROWS * D_BLR_PITCH];
-  const int f = blockIdx.y;
+  const int f = blockIdx.x;
   const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * (D_THREADS / 64) + (threadIdx.x >> 6);  // slot in the per-frame selected array
+  const int k = blockIdx.y * (D_THREADS / 64) + (threadIdx.x >> 6);  // slot in the per-frame selected array
   const int* cnt = sel_cnt + f * P.nlevels;
   if (k == 0 && lane == 0) {
     int tot = 0;
@@ -949,7 +952,7 @@ void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, c
 void launch_pyr_resize_tile(uint8_t* pyr, const Plan& P, int level, const uint32_t* xtp, const YTab* yt,
                             const int2* xrange, int ngx, const int2* yrange, int ngy, int src_rows, int src_pitch,
                             int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(pyr_resize_tile_kernel, dim3(ngx, ngy, nframes), dim3(PR_THREADS), (size_t)src_rows * src_pitch, st,
+  hipLaunchKernelGGL(pyr_resize_tile_kernel, dim3(nframes, ngy, ngx), dim3(PR_THREADS), (size_t)src_rows * src_pitch, st,
                      pyr, P.slab, P.lv[level - 1], P.lv[level], xtp, yt + P.lv[level].ytab_off, xrange, yrange,
                      src_pitch);
 }
@@ -962,7 +965,7 @@ void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int n
   int rows = 7;
   for (int l = 0; l < P.nlevels; l++) rows = max(rows, P.lv[l].hCell + 6);
   rows = min(rows, F_MAXH);
-  hipLaunchKernelGGL(fast_kernel, dim3(nitems, nframes), dim3(F_THREADS), 2 * (size_t)rows * F_PITCH, st, pyr, P, items,
+  hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), 2 * (size_t)rows * F_PITCH, st, pyr, P, items,
                      cand, cand_cnt, iniTh, minTh, rows);
 }
 template <int MAXS>
@@ -978,7 +981,7 @@ static hipError_t launch_octree_t(const uint32_t* cand, const int* cand_cnt, uin
       raised = true;
     }
   }
-  hipLaunchKernelGGL(octree_kernel<MAXS>, dim3(P.nlevels, nframes), dim3(OT_THREADS), lds, st, cand, cand_cnt, pnode,
+  hipLaunchKernelGGL(octree_kernel<MAXS>, dim3(nframes, P.nlevels), dim3(OT_THREADS), lds, st, cand, cand_cnt, pnode,
                      sel, sel_cnt, P);
   return hipSuccess;
 }
@@ -990,13 +993,13 @@ hipError_t launch_octree(const uint32_t* cand, const int* cand_cnt, uint32_t* pn
 }
 void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurItem* items, int nitems, const int* taps,
                  int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(blur_kernel, dim3(nitems, nframes), dim3(B_THREADS), 0, st, pyr, blur, P, items, taps[0], taps[1],
+  hipLaunchKernelGGL(blur_kernel, dim3(nframes, nitems), dim3(B_THREADS), 0, st, pyr, blur, P, items, taps[0], taps[1],
                      taps[2], taps[3]);
 }
 void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel, const int* sel_cnt, const Plan& P,
                         OrbKeyPoint* kps, uint8_t* desc, int* n_out, int max_kp, int nframes, hipStream_t st) {
   const int nb = (P.sel_total + (D_THREADS / 64) - 1) / (D_THREADS / 64);
-  hipLaunchKernelGGL(orient_desc_kernel, dim3(nb, nframes), dim3(D_THREADS), 0, st, pyr, blur, sel, sel_cnt, P, kps,
+  hipLaunchKernelGGL(orient_desc_kernel, dim3(nframes, nb), dim3(D_THREADS), 0, st, pyr, blur, sel, sel_cnt, P, kps,
                      desc, n_out, max_kp);
 }
 
