@@ -197,6 +197,27 @@ int orb_search_by_projection_mappoints(
     const float* mp_viewcos, const float* mp_projx, const float* mp_projy, const uint8_t* mp_desc,
     const int* mp_obs, float th, float nnratio, int* f_match, int* n_matches);
 
+/* The candidate scan shared by the two remaining projection searches,
+ *   SearchByProjection(Frame& Cur, KeyFrame*, const std::set<MapPoint*>&, th, ORBdist)
+ *     (src/ORBmatcher.cc:1800-1932: relocalisation; levels n-1..n+1, threshold ORBdist,
+ *      rotation check), and
+ *   SearchByProjection(KeyFrame*, cv::Mat Scw, const std::vector<MapPoint*>&, std::vector<MapPoint*>&, th)
+ *     (:394-524: loop closing; levels n-1..n, threshold TH_LOW, no rotation check).
+ * The caller projects its map points (pose algebra, distance gates and
+ * MapPoint::PredictScale, src/MapPoint.cc:593-633, stay on the host) and passes, per
+ * query in the reference's loop order, the window (u, v, radius), the level range of
+ * GetFeaturesInArea, the descriptor and q_active = "reached the candidate scan".
+ * t_taken marks train keypoints that already hold a map point; every accepted match
+ * (best distance <= max_dist, first minimum wins) takes its keypoint for later queries.
+ * t_match[idx] = query index, -1 untouched, -2 set and then nulled by the rotation check. */
+int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x,
+                       const float* t_y, const int* t_octave, const float* t_angle,
+                       const uint8_t* t_desc, const uint8_t* t_taken, int n_q,
+                       const uint8_t* q_active, const float* q_u, const float* q_v,
+                       const float* q_radius, const int* q_min_level, const int* q_max_level,
+                       const float* q_angle, const uint8_t* q_desc, int max_dist,
+                       int check_orientation, int* t_match, int* n_matches);
+
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)
  * (src/ORBmatcher.cc:853-1048).  The two DBoW2::FeatureVector maps arrive as sorted
  * node ids with CSR item lists; (ex, ey) is the epipole of KF1's centre in KF2

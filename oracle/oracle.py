@@ -250,6 +250,21 @@ def search_by_projection_mappoints(bounds, scale_factors, frame, mps, th, nnrati
     return n, match[:len(f_x)].copy()
 
 
+def match_windowed(bounds, train, queries, max_dist, check_ori):
+    """train: dict(x, y, octave, angle, desc, taken); queries: dict(active, u, v, r, minl, maxl, angle, desc)."""
+    t_x, t_y, t_o, t_a = _f32(train["x"]), _f32(train["y"]), _i32(train["octave"]), _f32(train["angle"])
+    t_d, t_t = _u8(train["desc"]), _u8(train["taken"])
+    q_a, q_u, q_v, q_r = _u8(queries["active"]), _f32(queries["u"]), _f32(queries["v"]), _f32(queries["r"])
+    q_lo, q_hi, q_ang, q_d = _i32(queries["minl"]), _i32(queries["maxl"]), _f32(queries["angle"]), _u8(queries["desc"])
+    match = np.empty(max(len(t_x), 1), np.int32)
+    f = C.c_float
+    n = lib().orc_match_windowed(f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]),
+                                 len(t_x), _p(t_x), _p(t_y), _p(t_o), _p(t_a), _p(t_d), _p(t_t),
+                                 len(q_a), _p(q_a), _p(q_u), _p(q_v), _p(q_r), _p(q_lo), _p(q_hi), _p(q_ang), _p(q_d),
+                                 int(max_dist), int(check_ori), _p(match))
+    return n, match[:len(t_x)].copy()
+
+
 def search_for_triangulation(kf1, kf2, fv1, fv2, F12, epipole, scale_factors2, level_sigma2_2, check_ori=False):
     """kf: dict(x, y, octave, angle, desc, has_mp); fv: dict(node, start, items)."""
     a = {}

@@ -944,6 +944,58 @@ ORC_API int orc_search_by_projection_mappoints(
   return nmatches;
 }
 
+/* Candidate scan common to SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist)
+ * (ORBmatcher.cc:1848-1897) and SearchByProjection(KeyFrame*, Scw, points, matched, th)
+ * (:470-520): per active query, GetFeaturesInArea with a level range, skip keypoints that
+ * hold a map point, strict '<' best, accept if best <= max_dist and take the keypoint;
+ * optional rotation histogram (:1880-1926). */
+ORC_API int orc_match_windowed(
+    float minX, float maxX, float minY, float maxY,
+    int nt, const float* t_x, const float* t_y, const int* t_oct, const float* t_angle, const uint8_t* t_desc,
+    const uint8_t* t_taken,
+    int nq, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_r, const int* q_minl,
+    const int* q_maxl, const float* q_angle, const uint8_t* q_desc, int max_dist, int check_ori, int* t_match) {
+  int nmatches = 0;
+  OrcGrid g;
+  grid_build(&g, nt, t_x, t_y, t_oct, minX, maxX, minY, maxY);
+  int* cand = (int*)malloc(sizeof(int) * (nt + 1));
+  uint8_t* taken = (uint8_t*)malloc(nt + 1);
+  int* hist_items = (int*)malloc(sizeof(int) * (size_t)(nq + 1));
+  int* hist_bin = (int*)malloc(sizeof(int) * (size_t)(nq + 1));
+  int nhist = 0;
+  for (int i = 0; i < nt; i++) { taken[i] = t_taken[i]; t_match[i] = -1; }
+  for (int i = 0; i < nq; i++) {
+    if (!q_active[i]) continue;
+    int nc = grid_query(&g, q_u[i], q_v[i], q_r[i], q_minl[i], q_maxl[i], cand);
+    if (nc == 0) continue;
+    int bestDist = 256, bestIdx = -1;
+    for (int k = 0; k < nc; k++) {
+      int idx = cand[k];
+      if (taken[idx]) continue;
+      const int dist = orc_descriptor_distance(q_desc + 32 * (size_t)i, t_desc + 32 * (size_t)idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= max_dist) {
+      t_match[bestIdx] = i;
+      taken[bestIdx] = 1;
+      nmatches++;
+      if (check_ori) { hist_items[nhist] = bestIdx; hist_bin[nhist] = rot_bin(q_angle[i] - t_angle[bestIdx]); nhist++; }
+    }
+  }
+  if (check_ori) {
+    int sizes[HISTO_LENGTH] = {0}, i1, i2, i3;
+    for (int k = 0; k < nhist; k++) sizes[hist_bin[k]]++;
+    orc_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+    for (int k = 0; k < nhist; k++) {
+      int b = hist_bin[k];
+      if (b != i1 && b != i2 && b != i3) { t_match[hist_items[k]] = -2; nmatches--; }
+    }
+  }
+  free(cand); free(taken); free(hist_items); free(hist_bin);
+  grid_free(&g);
+  return nmatches;
+}
+
 /* CheckDistEpipolarLine (ORBmatcher.cc:180-207) */
 static int check_dist_epipolar(float x1, float y1, float x2, float y2, const float* F12, float sigma2_kp2) {
   const float a = x1 * F12[0] + y1 * F12[3] + F12[6];

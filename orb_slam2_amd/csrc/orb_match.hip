@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, co
 // ---------------------------------------------------------------------------
 constexpr int MK = 4;  // ranked candidates kept per query
 constexpr int M_THREADS = 1024;
-enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2 };
+enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2, MODE_WINDOW = 3 };
 
 struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
@@ -166,6 +166,8 @@ struct MatchArgs {
   // query side
   const int* q_obs; const float* q_xw; const uint8_t* q_desc; const int* q_oct; const float* q_angle;
   const float* q_x; const float* q_y; const float* q_viewcos; const uint8_t* q_track;
+  const float* q_r; const int* q_minl; const int* q_maxl;  // WINDOW: radius and level range per query
+  int max_dist;                                            // WINDOW: accept threshold
   const int* q_idx1; const int* q_b0; const int* q_b1; const int* items2;  // TRIANG buckets
   const float* tcw;
   float fx, fy, cx, cy;
@@ -406,6 +408,12 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       geo.x = A.q_x[qbase + i]; geo.y = A.q_y[qbase + i]; geo.z = r * A.sf[lvl];
       geo.w = __int_as_float(((lvl - 1 + 1024) & 0xFFFF) | ((lvl + 1024) << 16));
       qdesc_ptr = A.q_desc + 32 * (qbase + i);
+    } else if constexpr (MODE == MODE_WINDOW) {
+      valid = A.q_track[qbase + i] != 0;
+      const int lo = min(max(A.q_minl[qbase + i], -1000), 1000), hi = min(max(A.q_maxl[qbase + i], -1000), 1000);
+      geo.x = A.q_x[qbase + i]; geo.y = A.q_y[qbase + i]; geo.z = A.q_r[qbase + i];
+      geo.w = __int_as_float(((lo + 1024) & 0xFFFF) | ((hi + 1024) << 16));
+      qdesc_ptr = A.q_desc + 32 * (qbase + i);
     } else {
       const int idx1 = A.q_idx1[qbase + i];
       b0 = A.q_b0[qbase + i]; b1 = A.q_b1[qbase + i];
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     }
     A.q_geo[qbase + i] = geo;
     int obs_bit = 0;
-    if (MODE != MODE_TRIANG) obs_bit = A.q_obs[qbase + i] > 0 ? 0x40000000 : 0;
+    if (MODE == MODE_FRAMES || MODE == MODE_MAPPOINTS) obs_bit = A.q_obs[qbase + i] > 0 ? 0x40000000 : 0;
     S.ntot[i] = valid ? (c.ntot | obs_bit) : -1;
 #pragma unroll
     for (int k = 0; k < MK; k++) S.lists[i * MK + k] = make_uint2(c.key[k], c.idx[k]);
@@ -499,6 +507,9 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
               if (l1 == l2 && (float)d1 > A.nnratio * (float)d2) accept = false;
             }
             occupy = accept && q_occupies;
+          } else if constexpr (MODE == MODE_WINDOW) {
+            accept = d1 <= A.max_dist;
+            occupy = accept;
           } else {
             accept = true;  // thresholds were applied during the scan
             occupy = true;
@@ -832,6 +843,40 @@ int orb_search_by_projection_mappoints(int device_id, OrbFrameBounds bounds, con
   int rc = run_match<MODE_MAPPOINTS>(A, 1, buf);
   if (rc != ORBHIP_OK) return rc;
   ORB_HIP_CHECK(hipMemcpy(f_match, A.out_match, sizeof(int) * n_f, hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
+                       const int* t_octave, const float* t_angle, const uint8_t* t_desc, const uint8_t* t_taken,
+                       int n_q, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_radius,
+                       const int* q_min_level, const int* q_max_level, const float* q_angle, const uint8_t* q_desc,
+                       int max_dist, int check_orientation, int* t_match, int* n_matches) {
+  if (!n_matches) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  *n_matches = 0;
+  if (n_t <= 0) return ORBHIP_OK;
+  if (n_t > 65535) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
+  if (!t_match || !t_x || !t_y || !t_octave || !t_desc || !t_taken) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if (n_q <= 0) { for (int i = 0; i < n_t; i++) t_match[i] = -1; return ORBHIP_OK; }
+  if (!q_active || !q_u || !q_v || !q_radius || !q_min_level || !q_max_level || !q_desc ||
+      (check_orientation && (!q_angle || !t_angle))) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  DevBuf buf;
+  MatchArgs A{};
+  A.max_q = n_q; A.max_t = n_t; A.nlevels = 1; A.check_ori = check_orientation; A.b = bounds; A.max_dist = max_dist;
+  std::vector<int> taken(n_t);
+  for (int i = 0; i < n_t; i++) taken[i] = t_taken[i] ? 1 : -1;
+  UP(buf, &n_q, 1, A.n_q); UP(buf, &n_t, 1, A.n_t);
+  UP(buf, q_active, n_q, A.q_track); UP(buf, q_u, n_q, A.q_x); UP(buf, q_v, n_q, A.q_y); UP(buf, q_radius, n_q, A.q_r);
+  UP(buf, q_min_level, n_q, A.q_minl); UP(buf, q_max_level, n_q, A.q_maxl); UP(buf, q_desc, (size_t)n_q * 32, A.q_desc);
+  UP(buf, t_x, n_t, A.t_x); UP(buf, t_y, n_t, A.t_y); UP(buf, t_octave, n_t, A.t_oct);
+  UP(buf, t_desc, (size_t)n_t * 32, A.t_desc); UP(buf, taken.data(), n_t, A.t_obs);
+  if (check_orientation) { UP(buf, q_angle, n_q, A.q_angle); UP(buf, t_angle, n_t, A.t_angle); }
+  else { A.q_angle = A.q_x; A.t_angle = A.t_x; }
+  UP(buf, (const int*)nullptr, n_t, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
+  int rc = run_match<MODE_WINDOW>(A, 1, buf);
+  if (rc != ORBHIP_OK) return rc;
+  ORB_HIP_CHECK(hipMemcpy(t_match, A.out_match, sizeof(int) * n_t, hipMemcpyDeviceToHost));
   ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
   return ORBHIP_OK;
 }

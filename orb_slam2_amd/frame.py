@@ -29,6 +29,27 @@ class MapPoint:
     def isBad(self):
         return self._bad
 
+    # scale-invariance range and viewing direction (reference src/MapPoint.cc:527-568);
+    # set by UpdateNormalAndDepth in the reference, plain attributes here
+    mfMinDistance = 0.0
+    mfMaxDistance = float("inf")
+    mNormalVector = np.array([0, 0, 1], np.float32)
+
+    def GetMinDistanceInvariance(self):
+        return np.float32(np.float32(0.8) * np.float32(self.mfMinDistance))
+
+    def GetMaxDistanceInvariance(self):
+        return np.float32(np.float32(1.2) * np.float32(self.mfMaxDistance))
+
+    def GetNormal(self):
+        return np.asarray(self.mNormalVector, np.float32)
+
+    def PredictScale(self, currentDist, frame):
+        """reference src/MapPoint.cc:593-633"""
+        ratio = np.float32(np.float32(self.mfMaxDistance) / np.float32(currentDist))
+        nScale = int(np.ceil(np.float32(np.log(ratio)) / np.float32(frame.mfLogScaleFactor)))
+        return min(max(nScale, 0), frame.mnScaleLevels - 1)
+
 
 class Frame:
     """Keypoints, descriptors, pose and map-point slots of one image."""
@@ -47,6 +68,9 @@ class Frame:
         self.mnMinX, self.mnMaxX, self.mnMinY, self.mnMaxY = (float(v) for v in bounds)
         self.mTcw = np.eye(4, dtype=np.float32) if Tcw is None else np.asarray(Tcw, np.float32).reshape(4, 4)
         self.mvpMapPoints = [None] * self.N
+        self.mnScaleLevels = len(self.mvScaleFactors)
+        self.mfScaleFactor = float(self.mvScaleFactors[1]) if self.mnScaleLevels > 1 else 1.2
+        self.mfLogScaleFactor = np.float32(np.log(np.float32(self.mfScaleFactor)))
 
 
 class KeyFrame(Frame):
@@ -59,6 +83,12 @@ class KeyFrame(Frame):
 
     def GetMapPoint(self, idx):
         return self.mvpMapPoints[idx]
+
+    def GetMapPointMatches(self):
+        return list(self.mvpMapPoints)
+
+    def IsInImage(self, x, y):
+        return self.mnMinX <= x < self.mnMaxX and self.mnMinY <= y < self.mnMaxY
 
     def GetRotation(self):
         return self.mTcw[:3, :3]

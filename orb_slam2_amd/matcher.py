@@ -61,9 +61,115 @@ class ORBmatcher:
 
     # ---- SearchByProjection(Frame&, const Frame&, th, bMono) (:1633) ----------------
     def SearchByProjection(self, *args):
+        """The four overloads of the reference (include/ORBmatcher.h:73,93,107,121),
+        told apart by their argument types."""
+        if len(args) >= 3 and isinstance(args[2], (set, frozenset)):
+            return self._search_reloc(*args)            # (Frame&, KeyFrame*, set, th, ORBdist)
+        if len(args) >= 2 and isinstance(args[1], np.ndarray):
+            return self._search_sim3(*args)             # (KeyFrame*, Scw, points, matched, th)
         if len(args) >= 2 and hasattr(args[1], "mvpMapPoints"):
-            return self._search_frames(*args)
-        return self._search_mappoints(*args)
+            return self._search_frames(*args)           # (Frame&, const Frame&, th, bMono)
+        return self._search_mappoints(*args)            # (Frame&, vector<MapPoint*>, th)
+
+    def _windowed(self, F, taken, q, max_dist, check_ori):
+        k = F.mvKeysUn
+        nq = len(q["active"])
+        match = np.full(max(F.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        b = FrameBounds(F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY)
+        check(self._lib.orb_match_windowed(
+            self.device, b, F.N, ptr(_f32(k["x"])), ptr(_f32(k["y"])), ptr(_i32(k["octave"])), ptr(_f32(k["angle"])),
+            ptr(F.mDescriptors), ptr(_u8(taken)), nq, ptr(_u8(q["active"])), ptr(_f32(q["u"])), ptr(_f32(q["v"])),
+            ptr(_f32(q["r"])), ptr(_i32(q["minl"])), ptr(_i32(q["maxl"])), ptr(_f32(q["angle"])), ptr(_u8(q["desc"])),
+            int(max_dist), int(check_ori), ptr(match), C.byref(nm)))
+        return nm.value, match
+
+    @staticmethod
+    def _blank_queries(n):
+        n = max(n, 1)
+        return dict(active=np.zeros(n, np.uint8), u=np.zeros(n, np.float32), v=np.zeros(n, np.float32),
+                    r=np.zeros(n, np.float32), minl=np.zeros(n, np.int32), maxl=np.zeros(n, np.int32),
+                    angle=np.zeros(n, np.float32), desc=np.zeros((n, 32), np.uint8))
+
+    # ---- SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist) (:1800) ----
+    def _search_reloc(self, CurrentFrame, pKF, sAlreadyFound, th, ORBdist):
+        f32 = np.float32
+        Rcw, tcw = CurrentFrame.mTcw[:3, :3], CurrentFrame.mTcw[:3, 3]
+        Ow = (-(Rcw.T.astype(f32) @ tcw)).astype(f32)
+        vpMPs = pKF.GetMapPointMatches()
+        q = self._blank_queries(len(vpMPs))
+        for i, pMP in enumerate(vpMPs):
+            if pMP is None or pMP.isBad() or pMP in sAlreadyFound:
+                continue
+            x3Dw = pMP.GetWorldPos()
+            x3Dc = _mat3_mul_add(Rcw, x3Dw, tcw)
+            invzc = f32(1.0 / np.float64(x3Dc[2])) if x3Dc[2] != 0 else f32(np.inf)
+            u = f32(f32(f32(f32(CurrentFrame.fx) * x3Dc[0]) * invzc) + f32(CurrentFrame.cx))
+            v = f32(f32(f32(f32(CurrentFrame.fy) * x3Dc[1]) * invzc) + f32(CurrentFrame.cy))
+            if u < CurrentFrame.mnMinX or u > CurrentFrame.mnMaxX or v < CurrentFrame.mnMinY or v > CurrentFrame.mnMaxY:
+                continue
+            PO = (x3Dw - Ow).astype(f32)
+            dist3D = f32(np.sqrt(np.float64(PO[0]) ** 2 + np.float64(PO[1]) ** 2 + np.float64(PO[2]) ** 2))  # cv::norm
+            if dist3D < pMP.GetMinDistanceInvariance() or dist3D > pMP.GetMaxDistanceInvariance():
+                continue
+            n = pMP.PredictScale(dist3D, CurrentFrame)
+            q["active"][i] = 1
+            q["u"][i], q["v"][i] = u, v
+            q["r"][i] = f32(f32(th) * CurrentFrame.mvScaleFactors[n])
+            q["minl"][i], q["maxl"][i] = n - 1, n + 1
+            q["angle"][i] = pKF.mvKeysUn["angle"][i]
+            q["desc"][i] = pMP.GetDescriptor()
+        taken = np.array([mp is not None for mp in CurrentFrame.mvpMapPoints] or [0], np.uint8)
+        nm, match = self._windowed(CurrentFrame, taken, q, ORBdist, self.mbCheckOrientation)
+        for i2 in range(CurrentFrame.N):
+            if match[i2] >= 0:
+                CurrentFrame.mvpMapPoints[i2] = vpMPs[match[i2]]
+            elif match[i2] == -2:
+                CurrentFrame.mvpMapPoints[i2] = None
+        return nm
+
+    # ---- SearchByProjection(KeyFrame*, cv::Mat Scw, points, matched, th) (:394) ----------
+    def _search_sim3(self, pKF, Scw, vpPoints, vpMatched, th):
+        f32 = np.float32
+        Scw = np.asarray(Scw, f32).reshape(4, 4)
+        sRcw = Scw[:3, :3]
+        scw = f32(np.sqrt(np.float64(f32(sRcw[0, 0] * sRcw[0, 0]) + f32(sRcw[0, 1] * sRcw[0, 1]) + f32(sRcw[0, 2] * sRcw[0, 2]))))
+        Rcw = (sRcw / scw).astype(f32)
+        tcw = (Scw[:3, 3] / scw).astype(f32)
+        Ow = (-(Rcw.T @ tcw)).astype(f32)
+        found = {id(mp) for mp in vpMatched if mp is not None}
+        q = self._blank_queries(len(vpPoints))
+        for i, pMP in enumerate(vpPoints):
+            if pMP.isBad() or id(pMP) in found:
+                continue
+            p3Dw = pMP.GetWorldPos()
+            p3Dc = _mat3_mul_add(Rcw, p3Dw, tcw)
+            if p3Dc[2] < 0.0:
+                continue
+            invz = f32(1.0) / p3Dc[2]
+            u = f32(f32(f32(pKF.fx) * f32(p3Dc[0] * invz)) + f32(pKF.cx))
+            v = f32(f32(f32(pKF.fy) * f32(p3Dc[1] * invz)) + f32(pKF.cy))
+            if not pKF.IsInImage(u, v):
+                continue
+            PO = (p3Dw - Ow).astype(f32)
+            dist = f32(np.sqrt(np.float64(PO[0]) ** 2 + np.float64(PO[1]) ** 2 + np.float64(PO[2]) ** 2))
+            if dist < pMP.GetMinDistanceInvariance() or dist > pMP.GetMaxDistanceInvariance():
+                continue
+            Pn = pMP.GetNormal()
+            if np.float64(f32(f32(f32(PO[0] * Pn[0]) + f32(PO[1] * Pn[1])) + f32(PO[2] * Pn[2]))) < 0.5 * np.float64(dist):
+                continue
+            n = pMP.PredictScale(dist, pKF)
+            q["active"][i] = 1
+            q["u"][i], q["v"][i] = u, v
+            q["r"][i] = f32(f32(th) * pKF.mvScaleFactors[n])
+            q["minl"][i], q["maxl"][i] = n - 1, n
+            q["desc"][i] = pMP.GetDescriptor()
+        taken = np.array([mp is not None for mp in vpMatched] or [0], np.uint8)
+        nm, match = self._windowed(pKF, taken, q, self.TH_LOW, False)
+        for idx in range(pKF.N):
+            if match[idx] >= 0:
+                vpMatched[idx] = vpPoints[match[idx]]
+        return nm
 
     def _search_frames(self, CurrentFrame, LastFrame, th, bMono=True):
         n, cur_match = self.search_by_projection_frames_batch([CurrentFrame], [LastFrame], th)

@@ -245,3 +245,87 @@ def test_knn2_merge_of_shards(oracle):
     rb, rs, ri, ra = oracle.knn2_bruteforce(q, db, 0.7)
     assert np.array_equal(out[0].cpu().numpy(), rb) and np.array_equal(out[1].cpu().numpy(), rs)
     assert np.array_equal(out[2].cpu().numpy(), ri) and np.array_equal(acc.cpu().numpy(), ra)
+
+
+def _windowed_case(rng, nt, nq, rows=480, cols=752):
+    tx, ty, to, ta, td = random_frame_arrays(rng, nt, rows, cols)
+    crowd = rng.integers(0, nt, nt // 4)
+    tx[crowd] = tx[crowd[0]] + rng.uniform(-12, 12, len(crowd)).astype(np.float32)
+    ty[crowd] = ty[crowd[0]] + rng.uniform(-12, 12, len(crowd)).astype(np.float32)
+    src = rng.integers(0, nt, nq)
+    lvl = np.clip(to[src] + rng.integers(-1, 2, nq), 0, 7).astype(np.int32)
+    sf, _ = scale_tables()
+    train = dict(x=tx, y=ty, octave=to, angle=ta, desc=td, taken=(rng.uniform(0, 1, nt) < 0.15).astype(np.uint8))
+    q = dict(active=(rng.uniform(0, 1, nq) < 0.9).astype(np.uint8),
+             u=(tx[src] + rng.uniform(-5, 5, nq)).astype(np.float32), v=(ty[src] + rng.uniform(-5, 5, nq)).astype(np.float32),
+             r=(np.float32(10) * sf[lvl]).astype(np.float32), minl=lvl - 1, maxl=lvl + rng.integers(0, 2, nq).astype(np.int32),
+             angle=((ta[src] + rng.normal(0, 10, nq)) % 360).astype(np.float32), desc=flip_bits(rng, td[src], 70))
+    return train, q, (0.0, float(cols), 0.0, float(rows))
+
+
+@pytest.mark.parametrize("seed,nt,nq,maxd,ori", [(0, 900, 700, 50, False), (1, 2000, 3000, 100, True), (2, 1500, 2500, 50, True)])
+def test_match_windowed_vs_oracle(oracle, seed, nt, nq, maxd, ori):
+    import ctypes as C
+    from orb_slam2_amd._lib import FrameBounds, check, lib, ptr
+    rng = np.random.default_rng(seed)
+    train, q, bounds = _windowed_case(rng, nt, nq)
+    want_n, want_m = oracle.match_windowed(bounds, train, q, maxd, ori)
+    match = np.zeros(nt, np.int32); nm = C.c_int()
+    f = lambda a, t: np.ascontiguousarray(a, t)
+    args = [f(train["x"], "f4"), f(train["y"], "f4"), f(train["octave"], "i4"), f(train["angle"], "f4"), f(train["desc"], "u1"),
+            f(train["taken"], "u1")]
+    qa = [f(q["active"], "u1"), f(q["u"], "f4"), f(q["v"], "f4"), f(q["r"], "f4"), f(q["minl"], "i4"), f(q["maxl"], "i4"),
+          f(q["angle"], "f4"), f(q["desc"], "u1")]
+    check(lib().orb_match_windowed(0, FrameBounds(*bounds), nt, *[ptr(a) for a in args], nq, *[ptr(a) for a in qa],
+                                   maxd, int(ori), ptr(match), C.byref(nm)))
+    assert want_n > 50 and nm.value == want_n and np.array_equal(match, want_m)
+
+
+def test_relocalisation_and_sim3_searches(oracle):
+    """The two remaining SearchByProjection overloads through the host mirror: the window
+    parameters come from the mirror's pose algebra, the scan from the GPU; compared with the
+    oracle's scan on the same windows and with the gates of the reference restated here."""
+    from orb_slam2_amd import Frame, KeyFrame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(11)
+    sf, s2 = scale_tables()
+    rows, cols, n = 480, 752, 1200
+    K = (np.float32(500), np.float32(500), np.float32(376), np.float32(240))
+    bounds = (0.0, float(cols), 0.0, float(rows))
+    x, y, o, a, d = random_frame_arrays(rng, n, rows, cols)
+    T = np.eye(4, dtype=np.float32); T[0, 3] = 0.1
+    cur = Frame(kp_struct(x, y, o, a), d, sf, s2, K, bounds, T)
+    kf = KeyFrame(kp_struct(x + 1, y, o, a), d, sf, s2, K, bounds, np.eye(4, dtype=np.float32))
+    mps = []
+    for i in range(n):
+        if rng.uniform() < 0.7:
+            Z = np.float32(rng.uniform(3, 20))
+            Xc = np.array([(x[i] - K[2]) / K[0] * Z, (y[i] - K[3]) / K[1] * Z, Z], np.float32)
+            mp = MapPoint(Xc - T[:3, 3], flip_bits(rng, d[i:i + 1], 40)[0], 1)
+            mp.mfMaxDistance = float(Z * sf[o[i]] * rng.uniform(0.9, 1.1)); mp.mfMinDistance = mp.mfMaxDistance / float(sf[7])
+            kf.mvpMapPoints[i] = mp
+            mps.append(mp)
+    already = set(mps[::17])
+    for i2 in range(0, n, 9):
+        cur.mvpMapPoints[i2] = MapPoint(np.zeros(3), d[i2])
+    before = list(cur.mvpMapPoints)
+    got = ORBmatcher(0.9, True).SearchByProjection(cur, kf, already, 10.0, 100)
+    new = [i2 for i2 in range(n) if cur.mvpMapPoints[i2] is not before[i2]]
+    assert got > 200 and len(new) >= got
+    for i2 in new:
+        mp = cur.mvpMapPoints[i2]
+        if mp is not None:
+            assert mp not in already and before[i2] is None
+            assert oracle.descriptor_distance(mp.GetDescriptor(), d[i2]) <= 100
+    # Sim3 variant: identity similarity with scale 2 (points twice as far in the keyframe's view)
+    S = np.eye(4, dtype=np.float32); S[:3, :3] *= 2
+    matched = [None] * n
+    for i2 in range(0, n, 7):
+        matched[i2] = mps[i2 % len(mps)]
+    pts = [mp for mp in mps if rng.uniform() < 0.8]
+    pre = list(matched)
+    got2 = ORBmatcher(0.75, True).SearchByProjection(kf, S, pts, matched, 10)
+    new2 = [i for i in range(n) if matched[i] is not pre[i]]
+    assert got2 == len(new2) and got2 > 100
+    for i in new2:
+        assert pre[i] is None and oracle.descriptor_distance(matched[i].GetDescriptor(), d[i]) <= 50
+        assert matched[i] not in [m for m in pre if m is not None]
