@@ -233,6 +233,15 @@ def main():
                "sample": "%d frames of the same sequence: oracle extraction + SearchByProjection on consecutive pairs" % n}
 
     if rank == 0:
+        # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh + tools/pmc_to_traffic.py),
+        # valid for the batch size they were taken at
+        traffic = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if tj["frames_per_launch"] == B:
+                traffic = {k.replace("_kernel", ""): v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
+        except (OSError, ValueError, KeyError):
+            pass
         ab = algorithmic_bytes(ROWS, COLS)
         names = ["pyramid", "fast", "quadtree", "blur", "orient_desc"]
         stages = {nm: round(float(ms), 4) for nm, ms in zip(names, stage_ms)}
@@ -249,8 +258,8 @@ def main():
                        "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": npairs,
                        "keypoints_per_frame": round(nkp / B, 1), "matches_per_pair": round(nmatch / npairs, 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(gbs[dom], 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(gbs[dom] / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_frame": ab[dom]},
+                         "unit": "GB/s", "frac": round(gbs[dom] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom),
+                         "algorithmic_bytes_per_launch": ab[dom] * B, "algorithmic_bytes_per_frame": ab[dom]},
             "stages_ms_per_step": stages,
             "stage_gbs": {k: round(v, 1) for k, v in gbs.items()},
             "cpu_baseline": cpu,

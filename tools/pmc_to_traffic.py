@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE and WRITE_SIZE passes of tools/prof_pmc.sh into the per-launch HBM
+traffic table bench.py reports (profiles/<tag>_traffic.json).
+
+FETCH_SIZE on gfx950 tallies the 128-byte read requests of the L2's memory side at 64 bytes
+(calibrated with tools/ubench/hbm_calib.hip for 1, 4 and 16 bytes per lane: the counter
+shows exactly half of the bytes read), so it is doubled; WRITE_SIZE is exact.  Both are in KiB.
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def mean_per_kernel(d, counter):
+    acc = defaultdict(list)
+    for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(fn)):
+            if row["Counter_Name"] == counter:
+                acc[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch_dir, write_dir, out, frames = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    f, w = mean_per_kernel(fetch_dir, "FETCH_SIZE"), mean_per_kernel(write_dir, "WRITE_SIZE")
+    table = {}
+    for k in sorted(f):
+        if not k.startswith("orbhip"):
+            continue
+        rd, wr = 2.0 * f[k] * 1024.0, w.get(k, 0.0) * 1024.0
+        table[k.replace("orbhip::", "")] = {"fetch_size_kib_raw": round(f[k], 1), "write_size_kib": round(w.get(k, 0.0), 1),
+                                            "read_bytes": round(rd), "write_bytes": round(wr), "hbm_bytes_per_launch": round(rd + wr)}
+    json.dump({"frames_per_launch": frames, "correction": "read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB",
+               "kernels": table}, open(out, "w"), indent=1)
+    print(json.dumps(table, indent=1))
+
+
+if __name__ == "__main__":
+    main()
