@@ -17,6 +17,7 @@ void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int
 void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, uint32_t*, int*, int, int, int, hipStream_t);
 hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, int, hipStream_t);
 void launch_blur(const uint8_t*, uint8_t*, const Plan&, const BlurItem*, int, const int*, int, hipStream_t);
+hipError_t upload_orient_tables();
 void launch_orient_desc(const uint8_t*, const uint8_t*, const uint32_t*, const int*, const Plan&, OrbKeyPoint*,
                         uint8_t*, int*, int, int, hipStream_t);
 void launch_pyr_resize_tile(uint8_t*, const Plan&, int, const uint32_t*, const YTab*, const int2*, int, const int2*, int,
@@ -421,6 +422,8 @@ int orb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini
   DeviceGuard g(device_id);
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate"); }
+  e = upload_orient_tables();
+  if (e != hipSuccess) { hipStreamDestroy(h->stream); delete h; return hip_fail(e, "hipMemcpyToSymbol"); }
   *out = h;
   return ORBHIP_OK;
 }

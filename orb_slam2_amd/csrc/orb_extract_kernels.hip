@@ -9,14 +9,9 @@
 // stages use _rn intrinsics so that no multiply-add is contracted.
 #include "orb_common.h"
 
-namespace orbhip {
+#include <vector>
 
-__constant__ int8_t c_pattern[256 * 4] = {
-#include "orb_pattern.inc"
-};
-// Half-widths of the rows of the radius-15 orientation disc (reference
-// src/ORBextractor.cc:544-572 evaluates to these values; checked on the host at start-up).
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+namespace orbhip {
 
 __device__ __forceinline__ int refl101(int i, int n) {
   i = i < 0 ? -i : i;
@@ -807,8 +802,44 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 constexpr int D_THREADS = 256;
-constexpr int D_RAW_ROWS = 31, D_RAW_PITCH = 36;  // 31 px + up to 3 bytes of alignment
+constexpr int D_RAW_ROWS = 32, D_RAW_PITCH = 44;  // 31 rows (+1 never weighted); 4 B margin + 40 B staged per row
 constexpr int D_BLR_ROWS = 37, D_BLR_PITCH = 40;  // 37 px + up to 3 bytes of alignment
+
+// Steering tables, filled by upload_orient_tables():
+//  d_patf[pair]      = (x0, x1, y0, y1) of the rBRIEF pair as floats;
+//  d_odw[row][half]  = weights of the 16 staged bytes a lane sums for the intensity centroid:
+//                      4 dwords of |u| (0 outside the disc) and 4 dwords of 0/1.
+__device__ float4 d_patf[256];
+__device__ uint32_t d_odw[32][2][8];
+
+// cos and sin of x in [0, 2*pi + small]: quadrant reduction and the classic double precision
+// minimax kernels on [-pi/4, pi/4] (error about 1e-16, so rounding the result to float gives
+// the correctly rounded float except in astronomically rare ties).
+__device__ __forceinline__ void sincos_small(double x, double& sn, double& cs) {
+  const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
+  r = __builtin_fma(-k, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  const double s = __builtin_fma(r * z, ps, r);
+  double pc = -1.13596475577881948265e-11;
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+  const int q = (int)k & 3;
+  sn = q == 0 ? s : q == 1 ? c : q == 2 ? -s : -c;
+  cs = q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
+}
+
+typedef float od_f2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* __restrict__ pyr,
                                                                 const uint8_t* __restrict__ blur,
@@ -816,11 +847,19 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
                                                                 const int* __restrict__ sel_cnt, Plan P,
                                                                 OrbKeyPoint* __restrict__ out_kps,
                                                                 uint8_t* __restrict__ out_desc,
-                                                                int* __restrict__ n_out, int max_kp) {
+                                                                int* __restrict__ n_out, int max_kp, int nframes,
+                                                                int nchunks) {
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[D_THREADS / 64][D_RAW_ROWS * D_RAW_PITCH + D_BLR_ROWS * D_BLR_PITCH];
-  const int f = blockIdx.x;
+  // Workgroups are handed to the 8 XCDs round-robin by linear index.  Give every XCD whole
+  // frames, one after the other, so that the patches its wavefronts gather stay in its L2.
+  const int w = blockIdx.x;
+  const int xcd = w & 7, slot = w >> 3;
+  const int f = (slot / nchunks) * 8 + xcd;
+  if (f >= nframes) return;
+  const int chunk = slot - (slot / nchunks) * nchunks;
   const int lane = threadIdx.x & 63;
-  const int k = blockIdx.y * (D_THREADS / 64) + (threadIdx.x >> 6);  // slot in the per-frame selected array
+  // slot in the per-frame selected array; uniform over the wavefront, so keep it scalar
+  const int k = __builtin_amdgcn_readfirstlane(chunk * (D_THREADS / 64) + (int)(threadIdx.x >> 6));
   const int* cnt = sel_cnt + f * P.nlevels;
   if (k == 0 && lane == 0) {
     int tot = 0;
@@ -835,84 +874,96 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   if (i >= cnt[l]) return;
   const int o = before + i;
   if (o >= max_kp) return;
-  const uint32_t v = sel_all[(size_t)f * P.sel_total + k];
+  const uint32_t v = __builtin_amdgcn_readfirstlane(sel_all[(size_t)f * P.sel_total + k]);
   const int cx = (int)(v & kCoordMask) + kBorder, cy = (int)((v >> kCoordBits) & kCoordMask) + kBorder;
   const size_t lvl = (size_t)f * P.slab + L.off + (size_t)(cy + kEdge) * L.pitch + cx + kXOff;
 
-  // pattern pairs of this lane (pair = lane + 64*j): issued early, used after the angle
-  uint32_t pat[4];
+  // tables of this lane, issued early: pattern pairs lane + 64*j, centroid weights
+  float4 pat[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) pat[j] = reinterpret_cast<const uint32_t*>(c_pattern)[lane + 64 * j];
+  for (int j = 0; j < 4; j++) pat[j] = d_patf[lane + 64 * j];
+  const int row = lane >> 1, half = lane & 1;
+  const uint4 wm = *reinterpret_cast<const uint4*>(&d_odw[row][half][0]);
+  const uint4 w1 = *reinterpret_cast<const uint4*>(&d_odw[row][half][4]);
 
   // Stage the two patches of this keypoint in the wave's LDS region with aligned dword
   // loads: rows -15..15 of the level (orientation disc) and rows -18..18 of the blurred
-  // level (a rotated pattern point reaches at most round(13*sqrt(2)) = 18 px).
+  // level (a rotated pattern point reaches at most round(13*sqrt(2)) = 18 px).  A lane
+  // moves half a row (5 dwords); the last 5 rows of the blurred patch take one more dword.
   uint8_t* s_raw = s_patch[threadIdx.x >> 6];
   uint8_t* s_blr = s_raw + D_RAW_ROWS * D_RAW_PITCH;
   const int al = (cx + kXOff - 15) & 3, al2 = (cx + kXOff - 18) & 3;
   {
-    const uint8_t* g = pyr + lvl - 15 - al;  // dword aligned: pitch and offsets are multiples of 4
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(pyr + lvl - 15 - al + (ptrdiff_t)(min(row, 30) - 15) * L.pitch) + 5 * half;
+    const uint32_t* gb = reinterpret_cast<const uint32_t*>(blur + lvl - 18 - al2 + (ptrdiff_t)(row - 18) * L.pitch) + 5 * half;
+    const int r2 = 32 + lane / 10, c2 = lane - (lane / 10) * 10;
+    const uint32_t* gc = reinterpret_cast<const uint32_t*>(blur + lvl - 18 - al2 + (ptrdiff_t)(min(r2, 36) - 18) * L.pitch) + c2;
+    uint32_t a0[5], b0[5];
 #pragma unroll
-    for (int it = 0; it < (D_RAW_ROWS * 9 + 63) / 64; it++) {
-      const int i = it * 64 + lane;
-      if (i < D_RAW_ROWS * 9) {
-        const int r = i / 9, c = i - r * 9;
-        *reinterpret_cast<uint32_t*>(&s_raw[r * D_RAW_PITCH + 4 * c]) =
-            *reinterpret_cast<const uint32_t*>(g + (ptrdiff_t)(r - 15) * L.pitch + 4 * c);
-      }
-    }
-    const uint8_t* gb = blur + lvl - 18 - al2;
+    for (int q = 0; q < 5; q++) a0[q] = g[q];
 #pragma unroll
-    for (int it = 0; it < (D_BLR_ROWS * 10 + 63) / 64; it++) {
-      const int i = it * 64 + lane;
-      if (i < D_BLR_ROWS * 10) {
-        const int r = i / 10, c = i - r * 10;
-        *reinterpret_cast<uint32_t*>(&s_blr[r * D_BLR_PITCH + 4 * c]) =
-            *reinterpret_cast<const uint32_t*>(gb + (ptrdiff_t)(r - 18) * L.pitch + 4 * c);
-      }
-    }
+    for (int q = 0; q < 5; q++) b0[q] = gb[q];
+    const uint32_t c0 = *gc;
+    uint32_t* dr = reinterpret_cast<uint32_t*>(&s_raw[row * D_RAW_PITCH + 4 + 20 * half]);
+    uint32_t* db = reinterpret_cast<uint32_t*>(&s_blr[row * D_BLR_PITCH + 20 * half]);
+#pragma unroll
+    for (int q = 0; q < 5; q++) dr[q] = a0[q];
+#pragma unroll
+    for (int q = 0; q < 5; q++) db[q] = b0[q];
+    if (lane < 50) *reinterpret_cast<uint32_t*>(&s_blr[r2 * D_BLR_PITCH + 4 * c2]) = c0;
   }
   __builtin_amdgcn_wave_barrier();
 
-  // intensity centroid: lane = 2*row + half
-  int m10 = 0, m01 = 0;
+  // intensity centroid: lane = 2*row + half sums 16 bytes of its row (u = -16..-1 or 0..15)
+  // with the weight table; m10 = sum u*I, m01 = v * sum I over the disc
+  int m10, m01;
   {
-    const int row = min(lane >> 1, 30), half = lane & 1;
-    const int vv = row - 15;
-    const int d = c_umax[vv < 0 ? -vv : vv];
-    const uint8_t* p = &s_raw[row * D_RAW_PITCH + 15 + al];
-    int sum = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const int u = half ? j : -1 - j;
-      const int au = half ? j : j + 1;
-      const int x = (au <= d && lane < 62) ? (int)p[u] : 0;
-      m10 += u * x;
-      sum += x;
-    }
-    m01 = vv * sum;
+    const int sb = row * D_RAW_PITCH + 3 + al + 16 * half;  // byte offset of the lane's first pixel
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(&s_raw[sb & ~3]);
+    const uint32_t x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3], x4 = q[4];
+    const uint32_t sh = (uint32_t)sb & 3u;
+    const uint32_t y0 = __builtin_amdgcn_alignbyte(x1, x0, sh), y1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
+    const uint32_t y2 = __builtin_amdgcn_alignbyte(x3, x2, sh), y3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
+    uint32_t su = __builtin_amdgcn_udot4(y0, wm.x, 0u, false);
+    su = __builtin_amdgcn_udot4(y1, wm.y, su, false);
+    su = __builtin_amdgcn_udot4(y2, wm.z, su, false);
+    su = __builtin_amdgcn_udot4(y3, wm.w, su, false);
+    uint32_t s1 = __builtin_amdgcn_udot4(y0, w1.x, 0u, false);
+    s1 = __builtin_amdgcn_udot4(y1, w1.y, s1, false);
+    s1 = __builtin_amdgcn_udot4(y2, w1.z, s1, false);
+    s1 = __builtin_amdgcn_udot4(y3, w1.w, s1, false);
+    m10 = half ? (int)su : -(int)su;
+    m01 = (row - 15) * (int)s1;
   }
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    m10 += __shfl_xor(m10, s);
-    m01 += __shfl_xor(m01, s);
-  }
+  // sum over the wavefront: within rows of 16 lanes by DPP, then the four row totals
+  auto wave_sum = [](int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false);  // row_ror 4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);  // row_ror 8
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+           __builtin_amdgcn_readlane(x, 48);
+  };
+  m10 = wave_sum(m10);
+  m01 = wave_sum(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-  // steered BRIEF on the blurred patch
+  // steered BRIEF on the blurred patch (two sample points per packed operation)
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float rad = __fmul_rn(angle, factorPI);
-  const float a = (float)cos((double)rad), b = (float)sin((double)rad);
+  double sn, cs;
+  sincos_small((double)rad, sn, cs);
+  const float a = (float)cs, b = (float)sn;
+  const od_f2 a2 = {a, a}, b2 = {b, b};
   const uint8_t* ctr = &s_blr[18 * D_BLR_PITCH + 18 + al2];
   int t0[4], t1[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int px0 = (int)(int8_t)(pat[j] & 0xFF), py0 = (int)(int8_t)((pat[j] >> 8) & 0xFF);
-    const int px1 = (int)(int8_t)((pat[j] >> 16) & 0xFF), py1 = (int)(int8_t)(pat[j] >> 24);
-    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn((float)px0, b), __fmul_rn((float)py0, a)));
-    const int q0 = __float2int_rn(__fsub_rn(__fmul_rn((float)px0, a), __fmul_rn((float)py0, b)));
-    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn((float)px1, b), __fmul_rn((float)py1, a)));
-    const int q1 = __float2int_rn(__fsub_rn(__fmul_rn((float)px1, a), __fmul_rn((float)py1, b)));
+    const od_f2 X = {pat[j].x, pat[j].y}, Y = {pat[j].z, pat[j].w};
+    const od_f2 r = X * b2 + Y * a2;  // row offsets of the two points
+    const od_f2 q = X * a2 - Y * b2;  // column offsets
+    const int r0 = __float2int_rn(r.x), r1 = __float2int_rn(r.y);
+    const int q0 = __float2int_rn(q.x), q1 = __float2int_rn(q.y);
     t0[j] = ctr[r0 * D_BLR_PITCH + q0];
     t1[j] = ctr[r1 * D_BLR_PITCH + q1];
   }
@@ -933,6 +984,33 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     kp.octave = l;
     out_kps[(size_t)f * max_kp + o] = kp;
   }
+}
+
+// Fills the steering tables on the current device.
+hipError_t upload_orient_tables() {
+  static const int8_t pattern[256 * 4] = {
+#include "orb_pattern.inc"
+  };
+  // half-widths of the rows of the radius-15 orientation disc (reference
+  // src/ORBextractor.cc:544-572 evaluates to these values; checked on the host at start-up)
+  static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  std::vector<float4> pf(256);
+  for (int i = 0; i < 256; i++)
+    pf[i] = make_float4((float)pattern[4 * i], (float)pattern[4 * i + 2], (float)pattern[4 * i + 1], (float)pattern[4 * i + 3]);
+  std::vector<uint32_t> wt(32 * 2 * 8, 0u);
+  for (int row = 0; row < 31; row++) {
+    const int d = umax[row < 15 ? 15 - row : row - 15];
+    for (int half = 0; half < 2; half++)
+      for (int bt = 0; bt < 16; bt++) {
+        const int au = half ? bt : 16 - bt;  // |u| of staged byte bt: u = bt - 16 (left half) or bt (right half)
+        if (au > d) continue;
+        wt[(row * 2 + half) * 8 + bt / 4] |= (uint32_t)au << (8 * (bt & 3));
+        wt[(row * 2 + half) * 8 + 4 + bt / 4] |= 1u << (8 * (bt & 3));
+      }
+  }
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(d_patf), pf.data(), sizeof(float4) * 256);
+  if (e != hipSuccess) return e;
+  return hipMemcpyToSymbol(HIP_SYMBOL(d_odw), wt.data(), sizeof(uint32_t) * wt.size());
 }
 
 // ---- launchers --------------------------------------------------------------
@@ -999,8 +1077,9 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurIte
 void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel, const int* sel_cnt, const Plan& P,
                         OrbKeyPoint* kps, uint8_t* desc, int* n_out, int max_kp, int nframes, hipStream_t st) {
   const int nb = (P.sel_total + (D_THREADS / 64) - 1) / (D_THREADS / 64);
-  hipLaunchKernelGGL(orient_desc_kernel, dim3(nframes, nb), dim3(D_THREADS), 0, st, pyr, blur, sel, sel_cnt, P, kps,
-                     desc, n_out, max_kp);
+  const int groups = (nframes + 7) / 8;  // frames are dealt to the 8 XCDs in groups
+  hipLaunchKernelGGL(orient_desc_kernel, dim3((unsigned)groups * 8u * (unsigned)nb), dim3(D_THREADS), 0, st, pyr, blur, sel,
+                     sel_cnt, P, kps, desc, n_out, max_kp, nframes, nb);
 }
 
 int fast_use_width() { return F_USEW; }
