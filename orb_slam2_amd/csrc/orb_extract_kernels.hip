@@ -802,8 +802,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 constexpr int D_THREADS = 256;
-constexpr int D_RAW_ROWS = 32, D_RAW_PITCH = 44;  // 31 rows (+1 never weighted); 4 B margin + 40 B staged per row
-constexpr int D_BLR_ROWS = 37, D_BLR_PITCH = 40;  // 37 px + up to 3 bytes of alignment
+constexpr int D_KPW = 4;  // keypoints per wavefront
+constexpr int D_RAW_ROWS = 32, D_BLR_ROWS = 48, D_PITCH = 64;  // staged rows (16 per load instruction), bytes per row
+constexpr int D_PAD = 16;                 // bytes in front of the level patch: its row 0 is read from offset -1
 
 // Steering tables, filled by upload_orient_tables():
 //  d_patf[pair]      = (x0, x1, y0, y1) of the rBRIEF pair as floats;
@@ -841,6 +842,23 @@ __device__ __forceinline__ void sincos_small(double x, double& sn, double& cs) {
 
 typedef float od_f2 __attribute__((ext_vector_type(2)));
 
+// The 16-byte pieces of a keypoint's two patches that one lane moves (see the kernel).
+struct Staged { uint4 a0, a1, b0, b1, b2; };
+__device__ __forceinline__ Staged od_issue(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t lvl,
+                                           int cx, int pitch, int rs, int seg) {
+  const int al = (cx + kXOff - 15) & 15, al2 = (cx + kXOff - 18) & 15;
+  const size_t step = (size_t)16 * pitch;
+  const uint8_t* g = pyr + lvl - 15 - al + (ptrdiff_t)(rs - 15) * pitch + 16 * seg;
+  const uint8_t* gb = blur + lvl - 18 - al2 + (ptrdiff_t)(rs - 18) * pitch + 16 * seg;
+  Staged s;
+  s.a0 = *reinterpret_cast<const uint4*>(g);
+  s.a1 = *reinterpret_cast<const uint4*>(g + step);
+  s.b0 = *reinterpret_cast<const uint4*>(gb);
+  s.b1 = *reinterpret_cast<const uint4*>(gb + step);
+  s.b2 = *reinterpret_cast<const uint4*>(gb + 2 * step);
+  return s;
+}
+
 __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* __restrict__ pyr,
                                                                 const uint8_t* __restrict__ blur,
                                                                 const uint32_t* __restrict__ sel_all,
@@ -849,7 +867,7 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
                                                                 uint8_t* __restrict__ out_desc,
                                                                 int* __restrict__ n_out, int max_kp, int nframes,
                                                                 int nchunks) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[D_THREADS / 64][D_RAW_ROWS * D_RAW_PITCH + D_BLR_ROWS * D_BLR_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[D_THREADS / 64][D_PAD + (D_RAW_ROWS + D_BLR_ROWS) * D_PITCH];
   // Workgroups are handed to the 8 XCDs round-robin by linear index.  Give every XCD whole
   // frames, one after the other, so that the patches its wavefronts gather stay in its L2.
   const int w = blockIdx.x;
@@ -858,68 +876,83 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   if (f >= nframes) return;
   const int chunk = slot - (slot / nchunks) * nchunks;
   const int lane = threadIdx.x & 63;
-  // slot in the per-frame selected array; uniform over the wavefront, so keep it scalar
-  const int k = __builtin_amdgcn_readfirstlane(chunk * (D_THREADS / 64) + (int)(threadIdx.x >> 6));
-  const int* cnt = sel_cnt + f * P.nlevels;
-  if (k == 0 && lane == 0) {
-    int tot = 0;
-    for (int l = 0; l < P.nlevels; l++) tot += cnt[l];
-    n_out[f] = tot;
-  }
-  if (k >= P.sel_total) return;
-  int l = 0, before = 0;
-  while (l + 1 < P.nlevels && k >= P.lv[l + 1].sel_off) { before += cnt[l]; l++; }
-  const LevelGeom& L = P.lv[l];
-  const int i = k - L.sel_off;
-  if (i >= cnt[l]) return;
-  const int o = before + i;
-  if (o >= max_kp) return;
-  const uint32_t v = __builtin_amdgcn_readfirstlane(sel_all[(size_t)f * P.sel_total + k]);
-  const int cx = (int)(v & kCoordMask) + kBorder, cy = (int)((v >> kCoordBits) & kCoordMask) + kBorder;
-  const size_t lvl = (size_t)f * P.slab + L.off + (size_t)(cy + kEdge) * L.pitch + cx + kXOff;
-
-  // tables of this lane, issued early: pattern pairs lane + 64*j, centroid weights
-  float4 pat[4];
+  // A wavefront takes D_KPW consecutive slots of the per-frame selected array, so that the
+  // steering tables (constant per lane) are fetched once for all of them.
+  const int k0 = __builtin_amdgcn_readfirstlane((chunk * (D_THREADS / 64) + (int)(threadIdx.x >> 6)) * D_KPW);
+  if (k0 >= P.sel_total) return;
+  // one round trip for everything needed to find the keypoints: the per-level counts
+  // (lane l holds level l) and the selected records (lane j holds slot k0 + j)
+  const int mycnt = lane < P.nlevels ? sel_cnt[f * P.nlevels + lane] : 0;
+  const uint32_t myv = (lane < D_KPW && k0 + lane < P.sel_total) ? sel_all[(size_t)f * P.sel_total + k0 + lane] : 0u;
+  float4 pat[4];  // pattern pairs lane + 64*j
 #pragma unroll
   for (int j = 0; j < 4; j++) pat[j] = d_patf[lane + 64 * j];
-  const int row = lane >> 1, half = lane & 1;
+  const int row = min(lane >> 1, 31), half = lane & 1;
   const uint4 wm = *reinterpret_cast<const uint4*>(&d_odw[row][half][0]);
   const uint4 w1 = *reinterpret_cast<const uint4*>(&d_odw[row][half][4]);
+  uint8_t* s_raw = s_patch[threadIdx.x >> 6] + D_PAD;
+  uint8_t* s_blr = s_raw + D_RAW_ROWS * D_PITCH;
 
-  // Stage the two patches of this keypoint in the wave's LDS region with aligned dword
-  // loads: rows -15..15 of the level (orientation disc) and rows -18..18 of the blurred
-  // level (a rotated pattern point reaches at most round(13*sqrt(2)) = 18 px).  A lane
-  // moves half a row (5 dwords); the last 5 rows of the blurred patch take one more dword.
-  uint8_t* s_raw = s_patch[threadIdx.x >> 6];
-  uint8_t* s_blr = s_raw + D_RAW_ROWS * D_RAW_PITCH;
-  const int al = (cx + kXOff - 15) & 3, al2 = (cx + kXOff - 18) & 3;
-  {
-    const uint32_t* g = reinterpret_cast<const uint32_t*>(pyr + lvl - 15 - al + (ptrdiff_t)(min(row, 30) - 15) * L.pitch) + 5 * half;
-    const uint32_t* gb = reinterpret_cast<const uint32_t*>(blur + lvl - 18 - al2 + (ptrdiff_t)(row - 18) * L.pitch) + 5 * half;
-    const int r2 = 32 + lane / 10, c2 = lane - (lane / 10) * 10;
-    const uint32_t* gc = reinterpret_cast<const uint32_t*>(blur + lvl - 18 - al2 + (ptrdiff_t)(min(r2, 36) - 18) * L.pitch) + c2;
-    uint32_t a0[5], b0[5];
+  // where slot k0 + kk lives: level, output row, centre; ok = false for empty slots
+  struct Loc { bool ok; int l, o, cx, cy, pitch; uint32_t v; size_t lvl; };
+  auto locate = [&](int kk) {
+    Loc q;
+    q.ok = false; q.l = 0; q.o = 0; q.cx = 0; q.cy = 0; q.pitch = 0; q.v = 0; q.lvl = 0;
+    const int k = k0 + kk;
+    if (kk >= D_KPW || k >= P.sel_total) return q;
+    q.v = __builtin_amdgcn_readlane(myv, kk);
+    int l = 0, before = 0, tot = 0, cnt_l = 0;
 #pragma unroll
-    for (int q = 0; q < 5; q++) a0[q] = g[q];
-#pragma unroll
-    for (int q = 0; q < 5; q++) b0[q] = gb[q];
-    const uint32_t c0 = *gc;
-    uint32_t* dr = reinterpret_cast<uint32_t*>(&s_raw[row * D_RAW_PITCH + 4 + 20 * half]);
-    uint32_t* db = reinterpret_cast<uint32_t*>(&s_blr[row * D_BLR_PITCH + 20 * half]);
-#pragma unroll
-    for (int q = 0; q < 5; q++) dr[q] = a0[q];
-#pragma unroll
-    for (int q = 0; q < 5; q++) db[q] = b0[q];
-    if (lane < 50) *reinterpret_cast<uint32_t*>(&s_blr[r2 * D_BLR_PITCH + 4 * c2]) = c0;
+    for (int j = 0; j < kMaxLevels; j++) {
+      const int c = __builtin_amdgcn_readlane(mycnt, j);
+      tot += c;
+      if (j < P.nlevels && k >= P.lv[j].sel_off) { l = j; cnt_l = c; before = tot - c; }
+    }
+    if (k == 0 && lane == 0) n_out[f] = tot;
+    const int i = k - P.lv[l].sel_off;
+    q.l = l; q.o = before + i;
+    q.ok = i < cnt_l && q.o < max_kp;
+    q.cx = (int)(q.v & kCoordMask) + kBorder; q.cy = (int)((q.v >> kCoordBits) & kCoordMask) + kBorder;
+    q.pitch = P.lv[l].pitch;
+    q.lvl = (size_t)f * P.slab + P.lv[l].off + (size_t)(q.cy + kEdge) * q.pitch + q.cx + kXOff;
+    return q;
+  };
+  // The two patches of a keypoint are staged in the wave's LDS region: rows -15..15 of the
+  // level (orientation disc) and rows -18..18 of the blurred level (a rotated pattern point
+  // reaches at most round(13*sqrt(2)) = 18 px), 64 bytes per row from a 16-byte aligned
+  // start.  A lane moves 16 bytes, a load instruction 16 rows, so a keypoint takes five of
+  // them; the rows staged beyond the patches (up to 29 below the centre) still lie in the
+  // slab's frame.  The loads of the next keypoint are issued before the current one is computed.
+  const int rs = lane >> 2, seg = lane & 3;
+  Staged st;
+  Loc cur = locate(0);
+  if (cur.ok) st = od_issue(pyr, blur, cur.lvl, cur.cx, cur.pitch, rs, seg);
+  for (int kk = 0; kk < D_KPW; kk++) {
+  const Loc nxt = locate(kk + 1);
+  if (!cur.ok) {
+    if (nxt.ok) st = od_issue(pyr, blur, nxt.lvl, nxt.cx, nxt.pitch, rs, seg);
+    cur = nxt;
+    continue;
   }
+  const uint32_t v = cur.v;
+  const int l = cur.l, o = cur.o, cx = cur.cx, cy = cur.cy;
+  const LevelGeom& L = P.lv[l];
+  const int al = (cx + kXOff - 15) & 15, al2 = (cx + kXOff - 18) & 15;
+  {
+    uint4* dr = reinterpret_cast<uint4*>(&s_raw[rs * D_PITCH + 16 * seg]);
+    uint4* db = reinterpret_cast<uint4*>(&s_blr[rs * D_PITCH + 16 * seg]);
+    dr[0] = st.a0; dr[16 * (D_PITCH / 16)] = st.a1;
+    db[0] = st.b0; db[16 * (D_PITCH / 16)] = st.b1; db[32 * (D_PITCH / 16)] = st.b2;
+  }
+  if (nxt.ok) st = od_issue(pyr, blur, nxt.lvl, nxt.cx, nxt.pitch, rs, seg);
   __builtin_amdgcn_wave_barrier();
 
   // intensity centroid: lane = 2*row + half sums 16 bytes of its row (u = -16..-1 or 0..15)
   // with the weight table; m10 = sum u*I, m01 = v * sum I over the disc
   int m10, m01;
   {
-    const int sb = row * D_RAW_PITCH + 3 + al + 16 * half;  // byte offset of the lane's first pixel
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(&s_raw[sb & ~3]);
+    const int sb = row * D_PITCH + al - 1 + 16 * half;  // byte offset of the lane's first pixel (-1 at most)
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(s_raw + (sb & ~3));
     const uint32_t x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3], x4 = q[4];
     const uint32_t sh = (uint32_t)sb & 3u;
     const uint32_t y0 = __builtin_amdgcn_alignbyte(x1, x0, sh), y1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
@@ -955,7 +988,7 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   sincos_small((double)rad, sn, cs);
   const float a = (float)cs, b = (float)sn;
   const od_f2 a2 = {a, a}, b2 = {b, b};
-  const uint8_t* ctr = &s_blr[18 * D_BLR_PITCH + 18 + al2];
+  const uint8_t* ctr = &s_blr[18 * D_PITCH + 18 + al2];
   int t0[4], t1[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -964,8 +997,8 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     const od_f2 q = X * a2 - Y * b2;  // column offsets
     const int r0 = __float2int_rn(r.x), r1 = __float2int_rn(r.y);
     const int q0 = __float2int_rn(q.x), q1 = __float2int_rn(q.y);
-    t0[j] = ctr[r0 * D_BLR_PITCH + q0];
-    t1[j] = ctr[r1 * D_BLR_PITCH + q1];
+    t0[j] = ctr[r0 * D_PITCH + q0];
+    t1[j] = ctr[r1 * D_PITCH + q1];
   }
   unsigned long long bits[4];
 #pragma unroll
@@ -984,6 +1017,8 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     kp.octave = l;
     out_kps[(size_t)f * max_kp + o] = kp;
   }
+  cur = nxt;
+  }  // keypoints of this wavefront
 }
 
 // Fills the steering tables on the current device.
@@ -1076,7 +1111,8 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurIte
 }
 void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel, const int* sel_cnt, const Plan& P,
                         OrbKeyPoint* kps, uint8_t* desc, int* n_out, int max_kp, int nframes, hipStream_t st) {
-  const int nb = (P.sel_total + (D_THREADS / 64) - 1) / (D_THREADS / 64);
+  const int per_wg = (D_THREADS / 64) * D_KPW;
+  const int nb = (P.sel_total + per_wg - 1) / per_wg;
   const int groups = (nframes + 7) / 8;  // frames are dealt to the 8 XCDs in groups
   hipLaunchKernelGGL(orient_desc_kernel, dim3((unsigned)groups * 8u * (unsigned)nb), dim3(D_THREADS), 0, st, pyr, blur, sel,
                      sel_cnt, P, kps, desc, n_out, max_kp, nframes, nb);
