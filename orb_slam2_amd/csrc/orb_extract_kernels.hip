@@ -19,26 +19,45 @@ __device__ __forceinline__ int refl101(int i, int n) {
 }
 
 // ---------------------------------------------------------------------------
-// Pyramid.  One thread writes 4 consecutive bytes of a padded slab row.
+// Pyramid.
 // Level 0: copy of the input with a 19-px BORDER_REFLECT_101 frame
-// (reference src/ORBextractor.cc:1406-1408).
+// (reference src/ORBextractor.cc:1406-1408).  One thread writes 16 consecutive bytes of
+// a padded slab row.  Input rows have any alignment (the stride need not be a multiple
+// of 4), so interior pieces are read as five aligned dwords and shifted into place;
+// pieces that touch the frame or the row ends go byte by byte.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restrict__ img, size_t stride,
                                                          size_t frame_stride, uint8_t* __restrict__ pyr,
                                                          unsigned long long slab, LevelGeom L) {
-  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c4 >= L.pitch) return;
-  const int row = blockIdx.y;  // padded row
-  const int f = blockIdx.z;
+  const int nchunk = L.pitch >> 4;
+  const int t = blockIdx.y * 256 + threadIdx.x;
+  const int row = t / nchunk;  // padded row
+  if (row >= L.h + 2 * kEdge) return;
+  const int c16 = (t - row * nchunk) * 16;
+  const int f = blockIdx.x;
   const int iy = refl101(row - kEdge, L.h);
   const uint8_t* S = img + (size_t)f * frame_stride + (size_t)iy * stride;
-  uint32_t out = 0;
+  const int px0 = c16 - kXOff;
+  uint4 out;
+  if (px0 >= 4 && px0 + 20 <= L.w) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(S + px0);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3], x4 = q[4];
+    out.x = __builtin_amdgcn_alignbyte(x1, x0, sh);
+    out.y = __builtin_amdgcn_alignbyte(x2, x1, sh);
+    out.z = __builtin_amdgcn_alignbyte(x3, x2, sh);
+    out.w = __builtin_amdgcn_alignbyte(x4, x3, sh);
+  } else {
+    uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int px = c4 + k - kXOff;
-    if (px >= -kEdge && px < L.w + kEdge) out |= (uint32_t)S[refl101(px, L.w)] << (8 * k);
+    for (int k = 0; k < 16; k++) {
+      const int px = px0 + k;
+      if (px >= -kEdge && px < L.w + kEdge) o[k >> 2] |= (uint32_t)S[refl101(px, L.w)] << (8 * (k & 3));
+    }
+    out = make_uint4(o[0], o[1], o[2], o[3]);
   }
-  *reinterpret_cast<uint32_t*>(pyr + (size_t)f * slab + L.off + (size_t)row * L.pitch + c4) = out;
+  *reinterpret_cast<uint4*>(pyr + (size_t)f * slab + L.off + (size_t)row * L.pitch + c16) = out;
 }
 
 // Level l >= 1: cv::resize(INTER_LINEAR, 8U fixed point) of level l-1's un-padded
@@ -1052,7 +1071,8 @@ hipError_t upload_orient_tables() {
 void launch_pyr_level0(const uint8_t* img, size_t stride, size_t frame_stride, uint8_t* pyr, const Plan& P,
                        int nframes, hipStream_t st) {
   const LevelGeom& L = P.lv[0];
-  dim3 grid((L.pitch / 4 + 255) / 256, L.h + 2 * kEdge, nframes);
+  const int pieces = (L.pitch / 16) * (L.h + 2 * kEdge);
+  dim3 grid(nframes, (pieces + 255) / 256);
   hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L);
 }
 void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, const YTab* yt, int nframes,
