@@ -157,6 +157,7 @@ enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2, MODE_WINDOW = 3 };
 struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
   int lists_in_lds;  // the ranked candidate lists of all queries fit in LDS next to the grid
+  int desc_in_lds;   // the train descriptors are staged in LDS (chosen before the lists)
   int ts, qs;  // element stride (4-byte units) of t_x/t_y/t_oct/t_angle and of q_oct/q_angle:
                // 1 for separate arrays, 6 for fields of OrbKeyPoint records
   const int* n_q; const int* n_t;
@@ -209,6 +210,7 @@ struct MatchShared {
   unsigned char* koct;   // max_t
   unsigned char* occ;    // max_t: train keypoint can no longer be taken
   int* claim;            // max_t: lowest pending lane that wants to take the keypoint
+  const uint4* tdesc;    // train descriptors, two uint4 each (LDS copy if it fits, else global)
   uint2* lists;          // max_q * MK ranked candidates (LDS if it fits, else global scratch)
   int* ntot;             // max_q: candidates seen (bit 30: the query's map point has observations), -1 = inactive
 };
@@ -220,7 +222,8 @@ template <int MODE>
 __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, int nt, const float4 geo,
                            const uint32_t* qd, int bucket0, int bucket1, float qx, float qy, Cand& c) {
   cand_init(c);
-  const uint4* tdesc = reinterpret_cast<const uint4*>(A.t_desc) + 2 * (size_t)pair * A.max_t;
+  const uint4* tdesc = S.tdesc;
+  (void)pair;
   if constexpr (MODE != MODE_TRIANG) {
     const float x = geo.x, y = geo.y, r = geo.z;
     const int lv = __float_as_int(geo.w);
@@ -237,22 +240,23 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
     if (nMaxCellY < 0) return;
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     int pos = 0;
-    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
-      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
-        const int cell = ix * GRID_ROWS + iy;
-        for (int p = S.start[cell]; p < S.start[cell + 1]; p++) {
-          const int j = S.items[p];
-          if (bCheckLevels) {
-            if ((int)S.koct[j] < minLevel) continue;
-            if (maxLevel >= 0 && (int)S.koct[j] > maxLevel) continue;
-          }
-          if (!(fabsf(S.kx[j] - x) < r && fabsf(S.ky[j] - y) < r)) continue;
-          const int mypos = pos++;
-          if (S.occ[j]) continue;
-          const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
-          cand_insert(c, ((uint32_t)d << 20) | (uint32_t)mypos, (uint32_t)j);
+    // the cells iy = nMinCellY..nMaxCellY of one grid column are adjacent in the CSR
+    // array, so a column of the window is one contiguous run of items
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+      const int pe = S.start[ix * GRID_ROWS + nMaxCellY + 1];
+      for (int p = S.start[ix * GRID_ROWS + nMinCellY]; p < pe; p++) {
+        const int j = S.items[p];
+        if (bCheckLevels) {
+          if ((int)S.koct[j] < minLevel) continue;
+          if (maxLevel >= 0 && (int)S.koct[j] > maxLevel) continue;
         }
+        if (!(fabsf(S.kx[j] - x) < r && fabsf(S.ky[j] - y) < r)) continue;
+        const int mypos = pos++;
+        if (S.occ[j]) continue;
+        const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+        cand_insert(c, ((uint32_t)d << 20) | (uint32_t)mypos, (uint32_t)j);
       }
+    }
     (void)nt;
   } else {
     // candidates: keyframe-2 features of the same vocabulary node, in order; the
@@ -307,6 +311,11 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     S.occ = p; p += (A.max_t + 3) & ~3;
     S.claim = reinterpret_cast<int*>(p); p += sizeof(int) * A.max_t;
     p = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
+    if (A.desc_in_lds) {
+      S.tdesc = reinterpret_cast<const uint4*>(p); p += 32 * (size_t)A.max_t;
+    } else {
+      S.tdesc = reinterpret_cast<const uint4*>(A.t_desc) + 2 * (size_t)pair * A.max_t;
+    }
     if (A.lists_in_lds) {
       S.lists = reinterpret_cast<uint2*>(p); p += sizeof(uint2) * MK * A.max_q;
       S.ntot = reinterpret_cast<int*>(p);
@@ -326,6 +335,11 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     S.occ[j] = (unsigned char)(A.t_obs[tbase + j] > 0);
     S.claim[j] = 0x7FFFFFFF;
     if (MODE != MODE_TRIANG) out_match[j] = -1;
+  }
+  if (A.desc_in_lds) {
+    const uint4* g = reinterpret_cast<const uint4*>(A.t_desc) + 2 * (size_t)pair * A.max_t;
+    uint4* d = const_cast<uint4*>(S.tdesc);
+    for (int j = tid; j < 2 * nt; j += M_THREADS) d[j] = g[j];
   }
   if (MODE == MODE_TRIANG)
     for (int i = tid; i < A.max_q; i += M_THREADS) out_match[i] = -1;
@@ -441,9 +455,20 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   // ---- phase B: replay the reference's query order, 64 queries per step
   if (tid < 64) {
     const int lane = tid;
+    // the lists of the next 64 queries are fetched while the current ones are replayed
+    // (they may live in global memory)
+    uint2 nl[MK];
+    int n_ntot = -1;
+    auto fetch = [&](int base) {
+      const int i = base + lane;
+      n_ntot = i < nq ? S.ntot[i] : -1;
+#pragma unroll
+      for (int k = 0; k < MK; k++) nl[k] = i < nq ? S.lists[i * MK + k] : make_uint2(0xFFFFFFFFu, 0u);
+    };
+    fetch(0);
     for (int base = 0; base < nq; base += 64) {
       const int i = base + lane;
-      const int nt_i = i < nq ? S.ntot[i] : -1;
+      const int nt_i = n_ntot;
       const bool active = nt_i > 0 && (nt_i & 0x3FFFFFFF) > 0;
       const bool q_occupies = (nt_i & 0x40000000) != 0;
       Cand c;
@@ -451,10 +476,11 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       int my_idx1 = 0;
       if (active) {
 #pragma unroll
-        for (int k = 0; k < MK; k++) { const uint2 e = S.lists[i * MK + k]; c.key[k] = e.x; c.idx[k] = e.y; }
+        for (int k = 0; k < MK; k++) { c.key[k] = nl[k].x; c.idx[k] = nl[k].y; }
         c.ntot = nt_i & 0x3FFFFFFF;
         if (MODE == MODE_TRIANG) my_idx1 = A.q_idx1[qbase + i];
       }
+      if (base + 64 < nq) fetch(base + 64);
       bool resolved = !active;
       while (true) {
         // first and second candidate that are still free
@@ -586,11 +612,12 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   if (tid == 0) A.n_matches[pair] = s_nm;
 }
 
-size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds) {
+size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds, bool desc_in_lds) {
   size_t n = sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + 2 * sizeof(float) * (size_t)max_t +
              sizeof(unsigned short) * (size_t)((max_t + 1) & ~1) + 2 * (size_t)((max_t + 3) & ~3) +
              sizeof(int) * (size_t)max_t + 32;
   if (lists_in_lds) n += (sizeof(uint2) * MK + sizeof(int)) * (size_t)max_q;
+  if (desc_in_lds) n += 32 * (size_t)max_t;
   return n;
 }
 
@@ -642,14 +669,18 @@ template <int MODE>
 int launch_match(const MatchArgs& A0, int n_pairs, hipStream_t st) {
   MatchArgs A = A0;
   constexpr size_t kLdsLimit = 156 * 1024;
-  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true) <= kLdsLimit;
-  const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0);
+  // descriptors first (every candidate reads them), then the ranked lists if there is room
+  A.desc_in_lds = match_lds_bytes(A.max_t, A.max_q, false, true) <= kLdsLimit;
+  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, A.desc_in_lds != 0) <= kLdsLimit;
+  const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0);
   if (lds > kLdsLimit) { set_error("too many train keypoints for the LDS-resident grid (limit about 9000)"); return ORBHIP_ERR_UNSUPPORTED; }
-  static bool raised = false;  // the attribute belongs to the function: raise it once to the limit
-  if (!raised) {
+  static bool raised[64] = {};  // per device: raise the function's dynamic LDS limit once
+  int dev = 0;
+  ORB_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !raised[dev]) {
     ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_kernel<MODE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    raised = true;
+    if (dev >= 0 && dev < 64) raised[dev] = true;
   }
   hipLaunchKernelGGL(match_kernel<MODE>, dim3(n_pairs), dim3(M_THREADS), lds, st, A);
   ORB_HIP_CHECK(hipGetLastError());
