@@ -499,17 +499,21 @@ struct OtShared {
   short x0[OT_MAXS], x1[OT_MAXS], y0[OT_MAXS], y1[OT_MAXS];
   int count[OT_MAXS];
   int key[OT_MAXS];
-  int ccount[OT_MAXS * 4];
-  short cslot[OT_MAXS * 4];
-  unsigned long long skey[OT_MAXS];
+  int ccount[OT_MAXS * 4];  // points per child; the output stage keeps the survivors' keys here
+  union {
+    short cslot[OT_MAXS * 4];          // slot of each child of a split node (steps 6-7)
+    unsigned long long skey[OT_MAXS];  // sort keys of an ordered round (step 3); best point per node (output stage)
+  };
   short elist[OT_MAXS];
   short order[OT_MAXS];
-  int cumg[OT_MAXS];
-  int cumc[OT_MAXS];
+  short cumg[OT_MAXS];   // prefix sums over the processing order: at most 3 resp. 4 per node
+  short cumc[OT_MAXS];
+  short bykey[OT_MAXS];  // slots of the nodes created by the last pass, by key - first key of that pass
   unsigned char split[OT_MAXS];
+  int wsum[OT_THREADS / 64];
   int vars[16];
 };
-enum { V_SIZE = 0, V_NSLOTS, V_NEXTSEQ, V_MODE, V_FINISH, V_NE, V_NEWEXP, V_PN, V_GROW, V_NCHILD };
+enum { V_SIZE = 0, V_NSLOTS, V_NEXTSEQ, V_MODE, V_FINISH, V_NE, V_NEWEXP, V_PN, V_GROW, V_NCHILD, V_K };
 
 template <int OT_MAXS>
 __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __restrict__ cand_all,
@@ -536,6 +540,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
     S.y0[tid] = 0;
     S.y1[tid] = (short)(L.maxBY - kBorder);
     S.key[tid] = nIni - 1 - tid;
+    S.bykey[nIni - 1 - tid] = (short)tid;
   }
   __syncthreads();
   for (int p = tid; p < n; p += OT_THREADS) {
@@ -554,6 +559,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
     S.vars[V_NEXTSEQ] = nIni;
     S.vars[V_MODE] = 0;
     S.vars[V_FINISH] = 0;
+    S.vars[V_K] = nIni;
   }
   __syncthreads();
 
@@ -565,16 +571,43 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
     if (finish) break;
     if (tid == 0) { S.vars[V_NE] = 0; S.vars[V_NEWEXP] = 0; }
     __syncthreads();
-    // 1. nodes that can be split
-    for (int s = tid; s < nslots; s += OT_THREADS) {
-      S.split[s] = 0;
-      if (S.count[s] > 1) {
-        S.elist[atomicAdd(&S.vars[V_NE], 1)] = (short)s;
-        S.ccount[4 * s] = 0; S.ccount[4 * s + 1] = 0; S.ccount[4 * s + 2] = 0; S.ccount[4 * s + 3] = 0;
+    // 1. nodes that can be split.  In a full pass every such node is split, in list order
+    // (descending key).  All of them were created by the previous pass, whose children sit
+    // in bykey[] by ascending key, so the processing order is a compaction of that array
+    // read backwards.  An ordered round collects them unordered and ranks them in step 3.
+    int E = 0;
+    for (int s = tid; s < nslots; s += OT_THREADS) S.split[s] = 0;
+    if (mode == 0) {
+      const int K = S.vars[V_K];
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int hi = K; hi > 0; hi -= OT_THREADS) {
+        const int idx = hi - 1 - tid;
+        int s = 0;
+        bool fl = false;
+        if (idx >= 0) { s = S.bykey[idx]; fl = S.count[s] > 1; }
+        const unsigned long long m = __ballot(fl);
+        if (lane == 0) S.wsum[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < OT_THREADS / 64; w++) { const int c = S.wsum[w]; all += c; if (w < wave) woff += c; }
+        if (fl) {
+          S.order[E + woff + __popcll(m & ((1ull << lane) - 1))] = (short)s;
+          S.ccount[4 * s] = 0; S.ccount[4 * s + 1] = 0; S.ccount[4 * s + 2] = 0; S.ccount[4 * s + 3] = 0;
+        }
+        E += all;
+        __syncthreads();
       }
+    } else {
+      for (int s = tid; s < nslots; s += OT_THREADS) {
+        if (S.count[s] > 1) {
+          S.elist[atomicAdd(&S.vars[V_NE], 1)] = (short)s;
+          S.ccount[4 * s] = 0; S.ccount[4 * s + 1] = 0; S.ccount[4 * s + 2] = 0; S.ccount[4 * s + 3] = 0;
+        }
+      }
+      __syncthreads();
+      E = S.vars[V_NE];
     }
-    __syncthreads();
-    const int E = S.vars[V_NE];
     // 2. quadrant of every point of such a node (DivideNode's point loop)
     for (int p = tid; p < n; p += OT_THREADS) {
       const int s = pn[p] & 0xFFFF;
@@ -587,23 +620,28 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
         atomicAdd(&S.ccount[4 * s + q], 1);
       }
     }
+    if (mode == 1)
+      for (int i = tid; i < E; i += OT_THREADS) {
+        const int s = S.elist[i];
+        S.skey[i] = ((unsigned long long)(unsigned)S.count[s] << 32) | (unsigned)S.key[s];
+      }
     __syncthreads();
-    // 3. processing order: rank by key (full pass) or by (count, key) (ordered round), descending
+    // 3. children per node along the processing order; an ordered round first ranks the
+    // nodes by (count, key) descending
     for (int i = tid; i < E; i += OT_THREADS) {
-      const int s = S.elist[i];
-      S.skey[i] = mode == 0 ? (unsigned long long)(unsigned)S.key[s]
-                            : (((unsigned long long)(unsigned)S.count[s] << 32) | (unsigned)S.key[s]);
-    }
-    __syncthreads();
-    for (int i = tid; i < E; i += OT_THREADS) {
-      const unsigned long long k = S.skey[i];
-      int r = 0;
-      for (int j = 0; j < E; j++) r += S.skey[j] > k;
-      const int s = S.elist[i];
-      S.order[r] = (short)s;
+      int r = i, s;
+      if (mode == 0) {
+        s = S.order[i];
+      } else {
+        const unsigned long long k = S.skey[i];
+        r = 0;
+        for (int j = 0; j < E; j++) r += S.skey[j] > k;
+        s = S.elist[i];
+        S.order[r] = (short)s;
+      }
       const int c = (S.ccount[4 * s] > 0) + (S.ccount[4 * s + 1] > 0) + (S.ccount[4 * s + 2] > 0) + (S.ccount[4 * s + 3] > 0);
-      S.cumg[r] = c - 1;
-      S.cumc[r] = c;
+      S.cumg[r] = (short)(c - 1);
+      S.cumc[r] = (short)c;
     }
     __syncthreads();
     // 4./5. prefix sums over the processing order; in an ordered round stop at the
@@ -619,7 +657,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
           if (tid >= o) { g += g2; c += c2; }
         }
         g += cg; c += cc;
-        if (i < E) { S.cumg[i] = g; S.cumc[i] = c; }
+        if (i < E) { S.cumg[i] = (short)g; S.cumc[i] = (short)c; }
         if (mode == 1 && pn_ < 0) {
           const unsigned long long hit = __ballot(i < E && size + g >= N);
           if (hit) pn_ = base + __ffsll((long long)hit);  // index of first hit + 1
@@ -657,6 +695,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
           S.y1[slot] = (short)((q & 2) ? Y1 : Y0 + hy);
           S.count[slot] = cc[q];
           S.key[slot] = nextseq + cbase + k;
+          S.bykey[cbase + k] = (short)slot;
           newexp += cc[q] > 1;
           k++;
         }
@@ -677,6 +716,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
       S.vars[V_SIZE] = newsize;
       S.vars[V_NSLOTS] = nslots + S.vars[V_GROW];
       S.vars[V_NEXTSEQ] = nextseq + S.vars[V_NCHILD];
+      S.vars[V_K] = S.vars[V_NCHILD];
       if (newsize >= N || newsize == size) S.vars[V_FINISH] = 1;
       else if (mode == 0 && newsize + 3 * S.vars[V_NEWEXP] > N) S.vars[V_MODE] = 1;
     }
@@ -698,12 +738,25 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
     atomicMax(&S.skey[s], k);
   }
   __syncthreads();
-  for (int s = tid; s < nslots; s += OT_THREADS) {
-    if (S.count[s] <= 0) continue;
-    const int k = S.key[s];
+  // surviving nodes, densely: slot list and keys; the output position of a node is its
+  // rank by key, descending (the order of the reference's list)
+  if (tid == 0) S.vars[V_NE] = 0;
+  __syncthreads();
+  for (int s = tid; s < nslots; s += OT_THREADS)
+    if (S.count[s] > 0) S.elist[atomicAdd(&S.vars[V_NE], 1)] = (short)s;
+  __syncthreads();
+  const int M = S.vars[V_NE];
+  int* kd = S.ccount;
+  for (int i = tid; i < ((M + 3) & ~3); i += OT_THREADS) kd[i] = i < M ? S.key[S.elist[i]] : -1;
+  __syncthreads();
+  for (int i = tid; i < M; i += OT_THREADS) {
+    const int k = kd[i];
     int r = 0;
-    for (int j = 0; j < nslots; j++) r += (S.count[j] > 0) && (S.key[j] > k);
-    const unsigned long long b = S.skey[s];
+    for (int j = 0; j < M; j += 4) {
+      const int4 q = *reinterpret_cast<const int4*>(&kd[j]);
+      r += (q.x > k) + (q.y > k) + (q.z > k) + (q.w > k);
+    }
+    const unsigned long long b = S.skey[S.elist[i]];
     const unsigned long long canon = ((1ull << 40) - 1) - (b & ((1ull << 40) - 1));
     const uint32_t x = (uint32_t)(canon & 0xFFF), y = (uint32_t)((canon >> 12) & 0xFFF);
     if (r < L.sel_cap) sel[r] = x | (y << kCoordBits) | ((uint32_t)(b >> 40) << 24);
