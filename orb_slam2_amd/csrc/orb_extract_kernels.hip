@@ -515,20 +515,43 @@ struct OtShared {
 };
 enum { V_SIZE = 0, V_NSLOTS, V_NEXTSEQ, V_MODE, V_FINISH, V_NE, V_NEWEXP, V_PN, V_GROW, V_NCHILD, V_K };
 
-template <int OT_MAXS>
-__global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __restrict__ cand_all,
-                                                            const int* __restrict__ cand_cnt,
-                                                            uint32_t* __restrict__ pnode_all,
-                                                            uint32_t* __restrict__ sel_all,
-                                                            int* __restrict__ sel_cnt, Plan P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ot_smem[];
-  OtShared<OT_MAXS>& S = *reinterpret_cast<OtShared<OT_MAXS>*>(ot_smem);
-  const int l = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+constexpr int OT_RPT = 8;  // points per thread that the register-resident form can hold
+
+// Visits the points of this thread: f(candidate record, node label&).  With REG the
+// records and labels live in registers (a thread always handles the same points); otherwise
+// they are read from, and labels written back to, global memory.
+template <bool REG, typename F>
+__device__ __forceinline__ void ot_for_points(int n, int tid, const uint32_t* __restrict__ pts, uint32_t* __restrict__ pn,
+                                              uint32_t (&rp)[OT_RPT], uint32_t (&rn)[OT_RPT], F f) {
+  if constexpr (REG) {
+#pragma unroll
+    for (int k = 0; k < OT_RPT; k++)
+      if (tid + k * OT_THREADS < n) f(rp[k], rn[k]);
+  } else {
+    for (int p = tid; p < n; p += OT_THREADS) {
+      const uint32_t w0 = pn[p];
+      uint32_t w = w0;
+      f(pts[p], w);
+      if (w != w0) pn[p] = w;
+    }
+  }
+}
+
+template <int OT_MAXS, bool REG>
+__device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t* __restrict__ pts,
+                                            uint32_t* __restrict__ pn, uint32_t* __restrict__ sel,
+                                            int* __restrict__ sel_cnt, const Plan& P, const int n, const int l,
+                                            const int f, const int tid) {
   const LevelGeom& L = P.lv[l];
-  const uint32_t* pts = cand_all + (size_t)f * P.cand_total + L.cand_off;
-  uint32_t* pn = pnode_all + (size_t)f * P.cand_total + L.cand_off;
-  uint32_t* sel = sel_all + (size_t)f * P.sel_total + L.sel_off;
-  const int n = min(cand_cnt[f * P.nlevels + l], L.cand_cap);
+  uint32_t rp[OT_RPT], rn[OT_RPT];
+  if constexpr (REG) {
+#pragma unroll
+    for (int k = 0; k < OT_RPT; k++) {
+      const int p = tid + k * OT_THREADS;
+      rp[k] = p < n ? pts[p] : 0u;
+      rn[k] = 0u;
+    }
+  }
   const int N = L.quota;
   const int nIni = L.nIni;
   const float hX = L.hX;
@@ -543,13 +566,15 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
     S.bykey[nIni - 1 - tid] = (short)tid;
   }
   __syncthreads();
-  for (int p = tid; p < n; p += OT_THREADS) {
-    const int x = pts[p] & kCoordMask;
+  if constexpr (!REG)
+    for (int p = tid; p < n; p += OT_THREADS) pn[p] = 0xFFFFFFFFu;  // so that the first label is always stored
+  ot_for_points<REG>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
+    const int x = v & kCoordMask;
     int r = (int)__fdiv_rn((float)x, hX);
     r = min(max(r, 0), nIni - 1);
-    pn[p] = (uint32_t)r;
+    node = (uint32_t)r;
     atomicAdd(&S.count[r], 1);
-  }
+  });
   __syncthreads();
   if (tid == 0) {
     int sz = 0;
@@ -609,17 +634,16 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
       E = S.vars[V_NE];
     }
     // 2. quadrant of every point of such a node (DivideNode's point loop)
-    for (int p = tid; p < n; p += OT_THREADS) {
-      const int s = pn[p] & 0xFFFF;
+    ot_for_points<REG>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
+      const int s = node & 0xFFFF;
       if (S.count[s] > 1) {
-        const uint32_t v = pts[p];
         const int x = v & kCoordMask, y = (v >> kCoordBits) & kCoordMask;
         const int hx = (S.x1[s] - S.x0[s] + 1) >> 1, hy = (S.y1[s] - S.y0[s] + 1) >> 1;
         const int q = (x < S.x0[s] + hx ? 0 : 1) + (y < S.y0[s] + hy ? 0 : 2);
-        pn[p] = (uint32_t)s | ((uint32_t)q << 16);
+        node = (uint32_t)s | ((uint32_t)q << 16);
         atomicAdd(&S.ccount[4 * s + q], 1);
       }
-    }
+    });
     if (mode == 1)
       for (int i = tid; i < E; i += OT_THREADS) {
         const int s = S.elist[i];
@@ -704,11 +728,10 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
     }
     __syncthreads();
     // 7. move the points of split nodes to their child
-    for (int p = tid; p < n; p += OT_THREADS) {
-      const uint32_t w = pn[p];
-      const int s = w & 0xFFFF;
-      if (S.split[s]) pn[p] = (uint32_t)(unsigned short)S.cslot[4 * s + (w >> 16)];
-    }
+    ot_for_points<REG>(n, tid, pts, pn, rp, rn, [&](uint32_t, uint32_t& node) {
+      const int s = node & 0xFFFF;
+      if (S.split[s]) node = (uint32_t)(unsigned short)S.cslot[4 * s + (node >> 16)];
+    });
     __syncthreads();
     // 8. loop control (src/ORBextractor.cc:891-897, 911, 992-993)
     if (tid == 0) {
@@ -728,15 +751,14 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
   const int nslots = S.vars[V_NSLOTS];
   for (int s = tid; s < nslots; s += OT_THREADS) S.skey[s] = 0;
   __syncthreads();
-  for (int p = tid; p < n; p += OT_THREADS) {
-    const int s = pn[p] & 0xFFFF;
-    const uint32_t v = pts[p];
+  ot_for_points<REG>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
+    const int s = node & 0xFFFF;
     const int x = v & kCoordMask, y = (v >> kCoordBits) & kCoordMask;
     const unsigned long long canon =
         ((unsigned long long)(((y - 3) / L.hCell) * 256 + (x - 3) / L.wCell) << 24) | ((unsigned)y << 12) | (unsigned)x;
     const unsigned long long k = ((unsigned long long)(v >> 24) << 40) | (((1ull << 40) - 1) - canon);
     atomicMax(&S.skey[s], k);
-  }
+  });
   __syncthreads();
   // surviving nodes, densely: slot list and keys; the output position of a node is its
   // rank by key, descending (the order of the reference's list)
@@ -762,6 +784,24 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
     if (r < L.sel_cap) sel[r] = x | (y << kCoordBits) | ((uint32_t)(b >> 40) << 24);
   }
   if (tid == 0) sel_cnt[f * P.nlevels + l] = min(S.vars[V_SIZE], L.sel_cap);
+}
+
+template <int OT_MAXS>
+__global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __restrict__ cand_all,
+                                                            const int* __restrict__ cand_cnt,
+                                                            uint32_t* __restrict__ pnode_all,
+                                                            uint32_t* __restrict__ sel_all,
+                                                            int* __restrict__ sel_cnt, Plan P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ot_smem[];
+  OtShared<OT_MAXS>& S = *reinterpret_cast<OtShared<OT_MAXS>*>(ot_smem);
+  const int l = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+  const LevelGeom& L = P.lv[l];
+  const uint32_t* pts = cand_all + (size_t)f * P.cand_total + L.cand_off;
+  uint32_t* pn = pnode_all + (size_t)f * P.cand_total + L.cand_off;
+  uint32_t* sel = sel_all + (size_t)f * P.sel_total + L.sel_off;
+  const int n = min(cand_cnt[f * P.nlevels + l], L.cand_cap);
+  if (n <= OT_RPT * OT_THREADS) octree_body<OT_MAXS, true>(S, pts, pn, sel, sel_cnt, P, n, l, f, tid);
+  else octree_body<OT_MAXS, false>(S, pts, pn, sel, sel_cnt, P, n, l, f, tid);
 }
 
 // ---------------------------------------------------------------------------
