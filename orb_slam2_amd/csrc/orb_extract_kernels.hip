@@ -202,27 +202,34 @@ __device__ __forceinline__ uint32_t as_u32(fast_s2 v) { return __builtin_bit_cas
 __device__ __forceinline__ fast_s2 pk_min(fast_s2 a, fast_s2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ fast_s2 pk_max(fast_s2 a, fast_s2 b) { return __builtin_elementwise_max(a, b); }
 
-// V = max(A, B) of the pixel at p (see above), on packed 16-bit lanes: every register
-// holds (d[k], -d[k]), so the sliding minima of d and of -d are computed together.
+// V = max(A, B) of the pixel at p (see above).  min over an arc of (c - p) is c - max over
+// the arc of p, so A = c - min_k max(p[k..k+8]) and B = max_k min(p[k..k+8]) - c: sliding
+// maxima and minima of the raw ring bytes.  On packed 16-bit lanes every register holds
+// (p[k], 255 - p[k]), so one max network yields both.
 __device__ __forceinline__ int fast_v(const uint8_t* p /* centre in LDS */) {
-  const uint32_t c2 = (uint32_t)p[0] * 0x10001u;
-  const fast_s2 sign = {1, -1};
+  const int c = p[0];
+  const fast_s2 flip = {0, 255};
   fast_s2 P[16];
   const int offs[16] = {3 * F_PITCH,      3 * F_PITCH + 1,  2 * F_PITCH + 2,  F_PITCH + 3,
                         3,                -F_PITCH + 3,     -2 * F_PITCH + 2, -3 * F_PITCH + 1,
                         -3 * F_PITCH,     -3 * F_PITCH - 1, -2 * F_PITCH - 2, -F_PITCH - 3,
                         -3,               F_PITCH - 3,      2 * F_PITCH - 2,  3 * F_PITCH - 1};
 #pragma unroll
-  for (int k = 0; k < 16; k++) P[k] = (as_s2(c2) - as_s2((uint32_t)p[offs[k]] * 0x10001u)) * sign;
+  for (int k = 0; k < 16; k++) {
+    const short v = (short)p[offs[k]];
+    const fast_s2 q = {v, v};
+    P[k] = q ^ flip;
+  }
   fast_s2 m2[16], m4[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) m2[k] = pk_min(P[k], P[(k + 1) & 15]);
+  for (int k = 0; k < 16; k++) m2[k] = pk_max(P[k], P[(k + 1) & 15]);
 #pragma unroll
-  for (int k = 0; k < 16; k++) m4[k] = pk_min(m2[k], m2[(k + 2) & 15]);
-  fast_s2 best = {-256, -256};
+  for (int k = 0; k < 16; k++) m4[k] = pk_max(m2[k], m2[(k + 2) & 15]);
+  fast_s2 best = {32767, 32767};
 #pragma unroll
-  for (int k = 0; k < 16; k++) best = pk_max(best, pk_min(pk_min(m4[k], m4[(k + 4) & 15]), P[(k + 8) & 15]));
-  return max((int)best.x, (int)best.y);
+  for (int k = 0; k < 16; k++) best = pk_min(best, pk_max(pk_max(m4[k], m4[(k + 4) & 15]), P[(k + 8) & 15]));
+  // best = (min_k max_arc p, 255 - max_k min_arc p)
+  return max(c - (int)best.x, 255 - (int)best.y - c);
 }
 
 // NMS decision for the pixel whose V byte is at q: strictly greater than the 8
@@ -312,7 +319,6 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     bool mine[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) mine[j] = colcell[j] >= 0 && ((cellmask >> colcell[j]) & 1u);
-    const fast_s2 t2 = {(short)t, (short)t};
     int qn = 0;  // wave-uniform: entries waiting in this wave's queue
 
     // full test of queue entries [0, n) (n <= 64 per call chunk), corners appended
@@ -348,24 +354,19 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       const uint32_t D = *reinterpret_cast<const uint32_t*>(rowp + 3 * F_PITCH);
       const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1);  // pixels x-3
       const uint32_t E = __builtin_amdgcn_alignbyte(R, C, 3);   // pixels x+3
-      uint32_t okbits = 0;
-#pragma unroll
-      for (int hsel = 0; hsel < 2; hsel++) {
-        const uint32_t sel = hsel ? 0x0c030c02u : 0x0c010c00u;  // bytes (0,1) or (2,3) widened to 16 bits
-        const fast_s2 c = as_s2(__builtin_amdgcn_perm(0u, C, sel));
-        const fast_s2 e0 = as_s2(__builtin_amdgcn_perm(0u, D, sel)) - c, e8 = as_s2(__builtin_amdgcn_perm(0u, U, sel)) - c;
-        const fast_s2 e4 = as_s2(__builtin_amdgcn_perm(0u, E, sel)) - c, e12 = as_s2(__builtin_amdgcn_perm(0u, W, sel)) - c;
-        // sign bit of (t - e) <=> brighter by more than t; of (t + e) <=> darker.  Nine
-        // contiguous ring pixels always contain two adjacent compass points:
-        // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12)
-        const uint32_t br = (as_u32(t2 - e0) | as_u32(t2 - e8)) & (as_u32(t2 - e4) | as_u32(t2 - e12));
-        const uint32_t dk = (as_u32(t2 + e0) | as_u32(t2 + e8)) & (as_u32(t2 + e4) | as_u32(t2 + e12));
-        const uint32_t r = br | dk;
-        okbits |= (((r >> 15) & 1u) | ((r >> 30) & 2u)) << (2 * hsel);
-      }
+      // per pixel: brighter / darker than the centre by more than t at the four compass
+      // points.  Nine contiguous ring pixels always contain two adjacent compass points:
+      // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12).  The comparisons are done per
+      // byte lane (byte-select operands), their results are wave masks combined on the scalar unit.
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const bool ok = mine[j] && ((okbits >> j) & 1u);
+        const int c = (int)((C >> (8 * j)) & 0xFFu);
+        const int hi = c + t, lo = c - t;
+        const int p0 = (int)((D >> (8 * j)) & 0xFFu), p8 = (int)((U >> (8 * j)) & 0xFFu);
+        const int p4 = (int)((E >> (8 * j)) & 0xFFu), p12 = (int)((W >> (8 * j)) & 0xFFu);
+        const bool br = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));
+        const bool dk = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo));
+        const bool ok = mine[j] & (br | dk);
         const unsigned long long m = __ballot(ok);
         if (ok) s_list[wave][qn + __popcll(m & lt_mask)] = (uint16_t)((y << 8) | (4 * lane + j));
         qn += __popcll(m);
