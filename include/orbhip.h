@@ -218,6 +218,22 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
                        const float* q_angle, const uint8_t* q_desc, int max_dist,
                        int check_orientation, int* t_match, int* n_matches);
 
+/* Stereo association, coarse stage, for the 752x480 stereo configuration.  No counterpart
+ * in this fork of the reference (its Frame has no ComputeStereoMatches); stated the way
+ * upstream ORB-SLAM2 states it, with this tree's ORBmatcher::DescriptorDistance and
+ * TH_HIGH / TH_LOW (src/ORBmatcher.cc:41-43, 1991-2011): a right keypoint is a candidate of
+ * the left keypoint iL if row (int)yL lies in floor(yR - r)..ceil(yR + r),
+ * r = 2 * scale_factors[octaveR], its octave is within one of octaveL, and
+ * xL - max_d <= xR <= xL - min_d; the first minimum of the distance in ascending right
+ * index wins and is a match if below th_dist (upstream: (TH_HIGH + TH_LOW) / 2 = 75).
+ * best_idx[iL] = right index or -1, best_dist[iL] = min(distance, TH_HIGH).
+ * Sub-pixel refinement is not included. */
+int orb_stereo_match(int device_id, int rows, int n_left, const float* l_x, const float* l_y,
+                     const int* l_octave, const uint8_t* l_desc, int n_right, const float* r_x,
+                     const float* r_y, const int* r_octave, const uint8_t* r_desc,
+                     const float* scale_factors, int nlevels, float min_d, float max_d,
+                     int th_dist, int* best_idx, int* best_dist, int* n_matches);
+
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)
  * (src/ORBmatcher.cc:853-1048).  The two DBoW2::FeatureVector maps arrive as sorted
  * node ids with CSR item lists; (ex, ey) is the epipole of KF1's centre in KF2

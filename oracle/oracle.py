@@ -265,6 +265,21 @@ def match_windowed(bounds, train, queries, max_dist, check_ori):
     return n, match[:len(t_x)].copy()
 
 
+def stereo_match(rows, left, right, scale_factors, min_d, max_d, th_dist=75):
+    """left / right: dicts with x, y, octave, desc.  Returns (n, best_idx, best_dist)."""
+    L = lib()
+    nl, nr = len(left["x"]), len(right["x"])
+    bi = np.full(max(nl, 1), -1, np.int32)
+    bd = np.zeros(max(nl, 1), np.int32)
+    lx, ly, lo, ld = _f32(left["x"]), _f32(left["y"]), _i32(left["octave"]), _u8(left["desc"])
+    rx, ry, ro, rd = _f32(right["x"]), _f32(right["y"]), _i32(right["octave"]), _u8(right["desc"])
+    sf = _f32(scale_factors)
+    L.orc_stereo_match.restype = C.c_int
+    n = L.orc_stereo_match(C.c_int(rows), C.c_int(nl), _p(lx), _p(ly), _p(lo), _p(ld), C.c_int(nr), _p(rx), _p(ry), _p(ro),
+                           _p(rd), _p(sf), C.c_float(min_d), C.c_float(max_d), C.c_int(th_dist), _p(bi), _p(bd))
+    return n, bi[:nl], bd[:nl]
+
+
 def search_for_triangulation(kf1, kf2, fv1, fv2, F12, epipole, scale_factors2, level_sigma2_2, check_ori=False):
     """kf: dict(x, y, octave, angle, desc, has_mp); fv: dict(node, start, items)."""
     a = {}

@@ -996,6 +996,67 @@ ORC_API int orc_match_windowed(
   return nmatches;
 }
 
+/* Coarse stage of stereo matching: per left keypoint the best right keypoint by Hamming
+ * distance inside a row band.  This fork of the reference has no stereo matcher (its
+ * Frame has no ComputeStereoMatches); the band search is stated here the way upstream
+ * ORB-SLAM2 states it, with this tree's DescriptorDistance and thresholds
+ * (src/ORBmatcher.cc:41-43): every right keypoint is listed in the rows
+ * floor(y - r)..ceil(y + r), r = 2 * scaleFactor[octave]; a left keypoint looks at the list
+ * of row (int)y, keeps right keypoints within one pyramid level and with
+ * uL - max_d <= uR <= uL - min_d, and takes the first minimum of the distance; it is a
+ * match if that minimum is below th_dist.  Sub-pixel refinement is not part of it.
+ * best_idx[iL] = right index or -1; best_dist[iL] = its distance (TH_HIGH if none). */
+ORC_API int orc_stereo_match(int rows, int n_left, const float* l_x, const float* l_y, const int* l_oct,
+                             const uint8_t* l_desc, int n_right, const float* r_x, const float* r_y, const int* r_oct,
+                             const uint8_t* r_desc, const float* scale_factors, float min_d, float max_d, int th_dist,
+                             int* best_idx, int* best_dist) {
+  /* row lists, in push order (ascending right index) */
+  int* cnt = (int*)calloc((size_t)rows + 1, sizeof(int));
+  for (int iR = 0; iR < n_right; iR++) {
+    const float r = 2.0f * scale_factors[r_oct[iR]];
+    const int maxr = (int)ceilf(r_y[iR] + r), minr = (int)floorf(r_y[iR] - r);
+    for (int yi = minr; yi <= maxr; yi++)
+      if (yi >= 0 && yi < rows) cnt[yi]++;
+  }
+  int* start = (int*)malloc(sizeof(int) * ((size_t)rows + 1));
+  int tot = 0;
+  for (int y = 0; y < rows; y++) { start[y] = tot; tot += cnt[y]; cnt[y] = 0; }
+  start[rows] = tot;
+  int* items = (int*)malloc(sizeof(int) * (size_t)(tot + 1));
+  for (int iR = 0; iR < n_right; iR++) {
+    const float r = 2.0f * scale_factors[r_oct[iR]];
+    const int maxr = (int)ceilf(r_y[iR] + r), minr = (int)floorf(r_y[iR] - r);
+    for (int yi = minr; yi <= maxr; yi++)
+      if (yi >= 0 && yi < rows) items[start[yi] + cnt[yi]++] = iR;
+  }
+  int nmatches = 0;
+  for (int iL = 0; iL < n_left; iL++) {
+    best_idx[iL] = -1;
+    best_dist[iL] = TH_HIGH;
+    const int levelL = l_oct[iL];
+    const float vL = l_y[iL], uL = l_x[iL];
+    const int row = (int)vL;
+    if (row < 0 || row >= rows) continue;
+    if (start[row + 1] == start[row]) continue;
+    const float minU = uL - max_d, maxU = uL - min_d;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH, bestIdxR = -1;
+    for (int k = start[row]; k < start[row + 1]; k++) {
+      const int iR = items[k];
+      if (r_oct[iR] < levelL - 1 || r_oct[iR] > levelL + 1) continue;
+      const float uR = r_x[iR];
+      if (uR >= minU && uR <= maxU) {
+        const int dist = orc_descriptor_distance(l_desc + 32 * (size_t)iL, r_desc + 32 * (size_t)iR);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    best_dist[iL] = bestDist;
+    if (bestDist < th_dist && bestIdxR >= 0) { best_idx[iL] = bestIdxR; nmatches++; }
+  }
+  free(cnt); free(start); free(items);
+  return nmatches;
+}
+
 /* CheckDistEpipolarLine (ORBmatcher.cc:180-207) */
 static int check_dist_epipolar(float x1, float y1, float x2, float y2, const float* F12, float sigma2_kp2) {
   const float a = x1 * F12[0] + y1 * F12[3] + F12[6];

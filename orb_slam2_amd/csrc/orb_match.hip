@@ -621,6 +621,113 @@ size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds, bool desc_in_lds
   return n;
 }
 
+// ---------------------------------------------------------------------------
+// Stereo row-band search: per left keypoint the best right keypoint by Hamming distance
+// among those whose row band floor(y - r)..ceil(y + r), r = 2 * scaleFactor[octave],
+// contains the left keypoint's row, within one pyramid level and the disparity range.
+// (This fork of the reference has no stereo matcher; the search is the coarse stage of
+// upstream ORB-SLAM2's stereo association with this tree's DescriptorDistance and
+// thresholds, src/ORBmatcher.cc:41-43.)  Left keypoints are independent of each other,
+// and the first minimum in ascending right index wins, so a workgroup per pair ranks
+// (distance, right index) in parallel.  Right keypoints are bucketed by their own row;
+// the rows a band can reach are adjacent, so the candidates of a left keypoint are one
+// contiguous run of the bucket array.
+// ---------------------------------------------------------------------------
+struct StereoArgs {
+  int max_l, max_r, rows, nlevels, band, desc_in_lds, th_dist;
+  const int* n_l; const int* n_r;
+  const float* l_x; const float* l_y; const int* l_oct; const uint8_t* l_desc;
+  const float* r_x; const float* r_y; const int* r_oct; const uint8_t* r_desc;
+  float sf[kMaxLevels];
+  float min_d, max_d;
+  int* best_idx; int* best_dist; int* n_matches;
+};
+
+__global__ __launch_bounds__(M_THREADS) void stereo_kernel(StereoArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_nm;
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int nl = min(A.n_l[pair], A.max_l), nr = min(A.n_r[pair], A.max_r);
+  unsigned char* p = smem;
+  int* start = reinterpret_cast<int*>(p); p += sizeof(int) * ((size_t)A.rows + 4);
+  float* rx = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_r;
+  float* ry = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_r;
+  unsigned short* items = reinterpret_cast<unsigned short*>(p); p += sizeof(unsigned short) * ((A.max_r + 1) & ~1);
+  unsigned char* roct = p; p += (A.max_r + 3) & ~3;
+  p = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
+  const uint4* rdesc = reinterpret_cast<const uint4*>(A.r_desc) + 2 * (size_t)pair * A.max_r;
+  if (A.desc_in_lds) {
+    uint4* d = reinterpret_cast<uint4*>(p);
+    for (int j = tid; j < 2 * nr; j += M_THREADS) d[j] = rdesc[j];
+    rdesc = d;
+  }
+  const size_t lbase = (size_t)pair * A.max_l, rbase = (size_t)pair * A.max_r;
+  // right keypoints into row buckets (counts at start[row + 2], scan, fill: as the grid of match_kernel)
+  for (int r = tid; r < A.rows + 2; r += M_THREADS) start[r] = 0;
+  if (tid == 0) s_nm = 0;
+  __syncthreads();
+  for (int j = tid; j < nr; j += M_THREADS) {
+    rx[j] = A.r_x[rbase + j]; ry[j] = A.r_y[rbase + j];
+    roct[j] = (unsigned char)min(max(A.r_oct[rbase + j], 0), A.nlevels - 1);
+    atomicAdd(&start[min(max((int)ry[j], 0), A.rows - 1) + 2], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int per = (A.rows + 63) / 64;
+    int sum = 0;
+    for (int k = 0; k < per; k++) { const int r = tid * per + k; if (r < A.rows) sum += start[r + 2]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (tid >= o) incl += v; }
+    int run = incl - sum;
+    for (int k = 0; k < per; k++) { const int r = tid * per + k; if (r < A.rows) { run += start[r + 2]; start[r + 2] = run; } }
+  }
+  __syncthreads();
+  for (int j = tid; j < nr; j += M_THREADS)
+    items[atomicAdd(&start[min(max((int)ry[j], 0), A.rows - 1) + 1], 1)] = (unsigned short)j;
+  __syncthreads();
+
+  for (int i = tid; i < nl; i += M_THREADS) {
+    const int levelL = A.l_oct[lbase + i];
+    const float vL = A.l_y[lbase + i], uL = A.l_x[lbase + i];
+    const int row = (int)vL;
+    uint32_t best = ((uint32_t)TH_HIGH << 16) | 0xFFFFu;
+    const float minU = uL - A.max_d, maxU = uL - A.min_d;
+    if (row >= 0 && row < A.rows && !(maxU < 0)) {
+      const uint4* ld = reinterpret_cast<const uint4*>(A.l_desc) + 2 * (lbase + i);
+      const uint4 d0 = ld[0], d1 = ld[1];
+      const uint32_t qd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      const int lo = max(row - A.band, 0), hi = min(row + A.band, A.rows - 1);
+      for (int q = start[lo]; q < start[hi + 1]; q++) {
+        const int j = items[q];
+        const int o = roct[j];
+        if (o < levelL - 1 || o > levelL + 1) continue;
+        const float r = 2.0f * A.sf[o];
+        const int maxr = (int)ceilf(ry[j] + r), minr = (int)floorf(ry[j] - r);
+        if (row < minr || row > maxr) continue;
+        const float uR = rx[j];
+        if (!(uR >= minU && uR <= maxU)) continue;
+        const uint32_t d = (uint32_t)hamming256(qd, rdesc[2 * j], rdesc[2 * j + 1]);
+        best = min(best, (d << 16) | (uint32_t)j);
+      }
+    }
+    const int bd = (int)(best >> 16);
+    const bool hit = bd < A.th_dist && bd < TH_HIGH;
+    A.best_dist[lbase + i] = min(bd, TH_HIGH);
+    A.best_idx[lbase + i] = hit ? (int)(best & 0xFFFFu) : -1;
+    if (hit) atomicAdd(&s_nm, 1);
+  }
+  __syncthreads();
+  if (tid == 0) A.n_matches[pair] = s_nm;
+}
+
+size_t stereo_lds_bytes(int rows, int max_r, bool desc_in_lds) {
+  size_t n = sizeof(int) * ((size_t)rows + 4) + 2 * sizeof(float) * (size_t)max_r +
+             sizeof(unsigned short) * (size_t)((max_r + 1) & ~1) + (size_t)((max_r + 3) & ~3) + 32;
+  if (desc_in_lds) n += 32 * (size_t)max_r;
+  return n;
+}
+
 // ---- host helpers -------------------------------------------------------------
 struct DevBuf {
   std::vector<void*> ptrs;
@@ -983,6 +1090,52 @@ int orb_search_for_triangulation(int device_id, int n1, const float* x1, const f
   std::vector<int> m(max_q);
   ORB_HIP_CHECK(hipMemcpy(m.data(), A.out_match, sizeof(int) * max_q, hipMemcpyDeviceToHost));
   std::copy(m.begin(), m.begin() + n1, matches12);
+  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_stereo_match(int device_id, int rows, int n_left, const float* l_x, const float* l_y, const int* l_octave,
+                     const uint8_t* l_desc, int n_right, const float* r_x, const float* r_y, const int* r_octave,
+                     const uint8_t* r_desc, const float* scale_factors, int nlevels, float min_d, float max_d,
+                     int th_dist, int* best_idx, int* best_dist, int* n_matches) {
+  if (!n_matches) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  *n_matches = 0;
+  if (n_left <= 0) return ORBHIP_OK;
+  if (!best_idx || !best_dist || !l_x || !l_y || !l_octave || !l_desc || !scale_factors) {
+    set_error("null argument"); return ORBHIP_ERR_ARG;
+  }
+  for (int i = 0; i < n_left; i++) { best_idx[i] = -1; best_dist[i] = TH_HIGH; }
+  if (n_right <= 0) return ORBHIP_OK;
+  if (!r_x || !r_y || !r_octave || !r_desc) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if (n_right > 65535 || rows < 1 || rows > 16384 || nlevels < 1 || nlevels > kMaxLevels) {
+    set_error("size out of range"); return ORBHIP_ERR_ARG;
+  }
+  StereoArgs A{};
+  A.max_l = n_left; A.max_r = n_right; A.rows = rows; A.nlevels = nlevels; A.th_dist = th_dist;
+  A.min_d = min_d; A.max_d = max_d;
+  float sfmax = 0.f;
+  for (int i = 0; i < nlevels; i++) { A.sf[i] = scale_factors[i]; sfmax = std::max(sfmax, scale_factors[i]); }
+  A.band = (int)std::ceil(2.0f * sfmax) + 2;  // rows between a right keypoint's own row and the ends of its band
+  constexpr size_t kLdsLimit = 156 * 1024;
+  A.desc_in_lds = stereo_lds_bytes(rows, n_right, true) <= kLdsLimit;
+  const size_t lds = stereo_lds_bytes(rows, n_right, A.desc_in_lds != 0);
+  if (lds > kLdsLimit) { set_error("too many right keypoints or rows for the LDS-resident row buckets"); return ORBHIP_ERR_UNSUPPORTED; }
+  DevSel g(device_id);
+  DevBuf buf;
+  UP(buf, &n_left, 1, A.n_l); UP(buf, &n_right, 1, A.n_r);
+  UP(buf, l_x, n_left, A.l_x); UP(buf, l_y, n_left, A.l_y); UP(buf, l_octave, n_left, A.l_oct);
+  UP(buf, l_desc, (size_t)n_left * 32, A.l_desc);
+  UP(buf, r_x, n_right, A.r_x); UP(buf, r_y, n_right, A.r_y); UP(buf, r_octave, n_right, A.r_oct);
+  UP(buf, r_desc, (size_t)n_right * 32, A.r_desc);
+  UP(buf, (const int*)nullptr, n_left, A.best_idx); UP(buf, (const int*)nullptr, n_left, A.best_dist);
+  UP(buf, (const int*)nullptr, 1, A.n_matches);
+  ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stereo_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+  hipLaunchKernelGGL(stereo_kernel, dim3(1), dim3(M_THREADS), lds, 0, A);
+  ORB_HIP_CHECK(hipGetLastError());
+  ORB_HIP_CHECK(hipDeviceSynchronize());
+  ORB_HIP_CHECK(hipMemcpy(best_idx, A.best_idx, sizeof(int) * n_left, hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpy(best_dist, A.best_dist, sizeof(int) * n_left, hipMemcpyDeviceToHost));
   ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
   return ORBHIP_OK;
 }

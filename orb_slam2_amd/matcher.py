@@ -298,6 +298,24 @@ class ORBmatcher:
         return nm.value
 
 
+def stereo_match(rows, left, right, scale_factors, min_d, max_d, th_dist=75, device=0):
+    """Coarse stereo association (row-band Hamming search; this fork of the reference has no
+    stereo matcher, see include/orbhip.h).  left / right: (keypoints KP_DTYPE, descriptors).
+    Returns (n_matches, best_idx[int32, -1 = none], best_dist[int32])."""
+    lk, ld = left
+    rk, rd = right
+    nl, nr = len(lk), len(rk)
+    sf = _f32(scale_factors)
+    bi = np.full(max(nl, 1), -1, np.int32)
+    bd = np.zeros(max(nl, 1), np.int32)
+    nm = C.c_int(0)
+    check(_lib.lib().orb_stereo_match(
+        device, int(rows), nl, ptr(_f32(lk["x"])), ptr(_f32(lk["y"])), ptr(_i32(lk["octave"])), ptr(_u8(ld)), nr,
+        ptr(_f32(rk["x"])), ptr(_f32(rk["y"])), ptr(_i32(rk["octave"])), ptr(_u8(rd)), ptr(sf), len(sf),
+        float(min_d), float(max_d), int(th_dist), ptr(bi), ptr(bd), C.byref(nm)))
+    return nm.value, bi[:nl], bd[:nl]
+
+
 def knn2_bruteforce(q, db, ratio=0.7, device=0):
     """Brute-force Hamming 2-nearest-neighbour search with ratio test on one GPU.
     Returns (best, second, idx, accept)."""

@@ -316,3 +316,36 @@ def test_search_by_projection_frames_properties(oracle):
         assert not Cu["obs"][i2] > 0  # occupied slots are never taken
     n2, m2 = oracle.search_by_projection_frames(sc["Tcw"], sc["K"], sc["bounds"], sc["sf"], sc["last"], sc["cur"], 7.0, True)
     assert n2 <= n and ((m2 == -2).sum() > 0) == (n2 < n)
+
+
+def test_stereo_band_search_against_definition(oracle):
+    """orc_stereo_match against the band definition evaluated pair by pair."""
+    import math
+    rng = np.random.default_rng(9)
+    rows, nl, nr = 90, 60, 80
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    L = dict(x=rng.uniform(0, 300, nl).astype(np.float32), y=rng.uniform(0, rows - 1, nl).astype(np.float32),
+             octave=rng.integers(0, 8, nl).astype(np.int32), desc=rng.integers(0, 256, (nl, 32), dtype=np.uint8))
+    R = dict(x=rng.uniform(0, 300, nr).astype(np.float32), y=rng.uniform(0, rows - 1, nr).astype(np.float32),
+             octave=rng.integers(0, 8, nr).astype(np.int32), desc=rng.integers(0, 256, (nr, 32), dtype=np.uint8))
+    R["desc"][:40] = L["desc"][:40] ^ np.uint8(1)          # planted near-duplicates
+    R["y"][:40] = L["y"][:40]; R["octave"][:40] = L["octave"][:40]
+    R["x"][:40] = L["x"][:40] - rng.uniform(0, 50, 40).astype(np.float32)
+    n, bi, bd = oracle.stereo_match(rows, L, R, sf, 0.0, 40.0, 75)
+    cnt = 0
+    for i in range(nl):
+        best, bj = 100, -1
+        for j in range(nr):
+            r = np.float32(2.0) * sf[R["octave"][j]]
+            lo, hi = math.floor(np.float32(R["y"][j] - r)), math.ceil(np.float32(R["y"][j] + r))
+            if not (lo <= int(L["y"][i]) <= hi) or abs(int(R["octave"][j]) - int(L["octave"][i])) > 1:
+                continue
+            if not (L["x"][i] - np.float32(40.0) <= R["x"][j] <= L["x"][i]):
+                continue
+            dd = int(np.unpackbits(L["desc"][i] ^ R["desc"][j]).sum())
+            if dd < best:
+                best, bj = dd, j
+        assert bd[i] == best
+        assert bi[i] == (bj if best < 75 else -1)
+        cnt += best < 75
+    assert n == cnt and cnt >= 20
