@@ -218,6 +218,25 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
                        const float* q_angle, const uint8_t* q_desc, int max_dist,
                        int check_orientation, int* t_match, int* n_matches);
 
+/* ORBmatcher::SearchByBoW, both overloads:
+ *   SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches)
+ *     (src/ORBmatcher.cc:222-381; accepts bestDist1 <= TH_LOW: pass max_dist = TH_LOW), and
+ *   SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12)
+ *     (:698-841; accepts bestDist1 < TH_LOW: pass max_dist = TH_LOW - 1).
+ * Side 1 is the keyframe whose features are visited (ok1 = has a map point that is not
+ * bad), side 2 the frame / second keyframe (ok2 = may be matched: 1 for every feature of a
+ * Frame, "has a good map point" for a keyframe).  Feature vectors as in
+ * orb_search_for_triangulation.  Best and second best are taken over the side-2 features of
+ * the same node not yet matched; accepted if best <= max_dist and
+ * (float)best < nnratio * (float)second.  matches12[idx1] = idx2 or -1 (the first overload
+ * stores the same pairs under idx2). */
+int orb_search_by_bow(int device_id, int n1, const float* angle1, const uint8_t* desc1,
+                      const uint8_t* ok1, int n2, const float* angle2, const uint8_t* desc2,
+                      const uint8_t* ok2, int n_nodes1, const int* node1, const int* start1,
+                      const int* items1, int n_nodes2, const int* node2, const int* start2,
+                      const int* items2, float nnratio, int max_dist, int check_orientation,
+                      int* matches12, int* n_matches);
+
 /* Stereo association, coarse stage, for the 752x480 stereo configuration.  No counterpart
  * in this fork of the reference (its Frame has no ComputeStereoMatches); stated the way
  * upstream ORB-SLAM2 states it, with this tree's ORBmatcher::DescriptorDistance and

@@ -302,6 +302,22 @@ def search_for_triangulation(kf1, kf2, fv1, fv2, F12, epipole, scale_factors2, l
     return n, m12[:n1].copy()
 
 
+def search_by_bow(s1, s2, fv1, fv2, nnratio, max_dist, check_ori=True):
+    """s1 / s2: dict(angle, desc, ok); fv: dict(node, start, items).  Returns (n, matches12)."""
+    a1, d1, k1 = _f32(s1["angle"]), _u8(s1["desc"]), _u8(s1["ok"])
+    a2, d2, k2 = _f32(s2["angle"]), _u8(s2["desc"]), _u8(s2["ok"])
+    n1, n2 = len(a1), len(a2)
+    nd1, st1, it1 = _i32(fv1["node"]), _i32(fv1["start"]), _i32(fv1["items"])
+    nd2, st2, it2 = _i32(fv2["node"]), _i32(fv2["start"]), _i32(fv2["items"])
+    m12 = np.full(max(n1, 1), -1, np.int32)
+    L = lib()
+    L.orc_search_by_bow.restype = C.c_int
+    n = L.orc_search_by_bow(C.c_int(n1), _p(a1), _p(d1), _p(k1), C.c_int(n2), _p(a2), _p(d2), _p(k2),
+                            C.c_int(len(nd1)), _p(nd1), _p(st1), _p(it1), C.c_int(len(nd2)), _p(nd2), _p(st2), _p(it2),
+                            C.c_float(nnratio), C.c_int(max_dist), C.c_int(int(check_ori)), _p(m12))
+    return n, m12[:n1].copy()
+
+
 def knn2_bruteforce(q, db, ratio):
     q, db = _u8(q), _u8(db)
     nq = len(q)

@@ -1138,6 +1138,67 @@ ORC_API int orc_search_for_triangulation(
   return nmatches;
 }
 
+/* ORBmatcher::SearchByBoW, both overloads:
+ *   (KeyFrame* pKF, Frame& F, vector<MapPoint*>&)          ORBmatcher.cc:222-381  accept bestDist1 <= TH_LOW
+ *   (KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>&)   ORBmatcher.cc:698-841  accept bestDist1 <  TH_LOW
+ * restated on flat arrays.  ok1[idx1]: the feature of side 1 has a good map point (:266-272,
+ * :740-744).  ok2[idx2]: the feature of side 2 may be matched at all (always for a Frame;
+ * "has a good map point" for a keyframe, :757-764).  A matched side-2 feature is skipped by
+ * later queries (:285 resp. :760).  max_dist = TH_LOW resp. TH_LOW - 1.
+ * matches12[idx1] = idx2 or -1 (the first overload stores the pair under idx2: the same pairs). */
+ORC_API int orc_search_by_bow(int n1, const float* ang1, const uint8_t* desc1, const uint8_t* ok1, int n2, const float* ang2,
+                              const uint8_t* desc2, const uint8_t* ok2, int nnodes1, const int* node1, const int* start1,
+                              const int* items1, int nnodes2, const int* node2, const int* start2, const int* items2,
+                              float nnratio, int max_dist, int check_ori, int* matches12) {
+  int nmatches = 0;
+  uint8_t* matched2 = (uint8_t*)calloc(n2 + 1, 1);
+  int* hist_items = (int*)malloc(sizeof(int) * (n1 + 1));
+  int* hist_bin = (int*)malloc(sizeof(int) * (n1 + 1));
+  int nhist = 0;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  int f1 = 0, f2 = 0;
+  while (f1 < nnodes1 && f2 < nnodes2) {
+    if (node1[f1] == node2[f2]) {
+      for (int p1 = start1[f1]; p1 < start1[f1 + 1]; p1++) {
+        const int idx1 = items1[p1];
+        if (!ok1[idx1]) continue;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int p2 = start2[f2]; p2 < start2[f2 + 1]; p2++) {
+          const int idx2 = items2[p2];
+          if (matched2[idx2] || !ok2[idx2]) continue;
+          const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= max_dist && (float)bestDist1 < nnratio * (float)bestDist2) {
+          matches12[idx1] = bestIdx2;
+          matched2[bestIdx2] = 1;
+          if (check_ori) { hist_items[nhist] = idx1; hist_bin[nhist] = rot_bin(ang1[idx1] - ang2[bestIdx2]); nhist++; }
+          nmatches++;
+        }
+      }
+      f1++; f2++;
+    } else if (node1[f1] < node2[f2]) {
+      while (f1 < nnodes1 && node1[f1] < node2[f2]) f1++; /* lower_bound */
+    } else {
+      while (f2 < nnodes2 && node2[f2] < node1[f1]) f2++;
+    }
+  }
+  if (check_ori) {
+    int sizes[HISTO_LENGTH] = {0}, i1, i2, i3;
+    for (int k = 0; k < nhist; k++) sizes[hist_bin[k]]++;
+    orc_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+    for (int k = 0; k < nhist; k++) {
+      int b = hist_bin[k];
+      if (b == i1 || b == i2 || b == i3) continue;
+      matches12[hist_items[k]] = -1;
+      nmatches--;
+    }
+  }
+  free(matched2); free(hist_items); free(hist_bin);
+  return nmatches;
+}
+
 /* Brute-force Hamming kNN-2 with the accept-form ratio test used by the reference's
  * BoW / initialisation matchers ((float)best < ratio*(float)second, e.g.
  * ORBmatcher.cc:312,616): sequential scan, strict '<' so the lowest index wins ties.

@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, co
 // ---------------------------------------------------------------------------
 constexpr int MK = 4;  // ranked candidates kept per query
 constexpr int M_THREADS = 1024;
-enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2, MODE_WINDOW = 3 };
+enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2, MODE_WINDOW = 3, MODE_BOW = 4 };
+// TRIANG and BOW take their candidates from vocabulary-node buckets instead of the grid and
+// index the output by the feature of side 1
+constexpr bool mode_bucketed(int mode) { return mode == MODE_TRIANG || mode == MODE_BOW; }
 
 struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
@@ -224,7 +227,7 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
   cand_init(c);
   const uint4* tdesc = S.tdesc;
   (void)pair;
-  if constexpr (MODE != MODE_TRIANG) {
+  if constexpr (!mode_bucketed(MODE)) {
     const float x = geo.x, y = geo.y, r = geo.z;
     const int lv = __float_as_int(geo.w);
     const int minLevel = (lv & 0xFFFF) - 1024, maxLevel = (lv >> 16) - 1024;
@@ -266,6 +269,11 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
       const int j = A.items2[p];
       if (S.occ[j]) continue;
       const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+      if constexpr (MODE == MODE_BOW) {
+        // SearchByBoW keeps best and second over the whole bucket; the first minimum wins
+        cand_insert(c, ((uint32_t)d << 20) | (uint32_t)pos, (uint32_t)j);
+        continue;
+      }
       if (d > TH_LOW) continue;
       const float x2 = S.kx[j], y2 = S.ky[j];
       const float distex = A.ex - x2, distey = A.ey - y2;
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     }
   }
   const size_t tbase = (size_t)pair * A.max_t, qbase = (size_t)pair * A.max_q;
-  int* out_match = A.out_match + (MODE == MODE_TRIANG ? qbase : tbase);
+  int* out_match = A.out_match + (mode_bucketed(MODE) ? qbase : tbase);
 
   // ---- phase 0: train keypoints to LDS; 64x48 grid as CSR in insertion order
   // (Frame::AssignFeaturesToGrid / PosInGrid, reference src/Frame.cc:190-213, 461-477)
@@ -334,18 +342,18 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     S.koct[j] = (unsigned char)min(max(A.t_oct[(tbase + j) * A.ts], 0), 255);
     S.occ[j] = (unsigned char)(A.t_obs[tbase + j] > 0);
     S.claim[j] = 0x7FFFFFFF;
-    if (MODE != MODE_TRIANG) out_match[j] = -1;
+    if (!mode_bucketed(MODE)) out_match[j] = -1;
   }
   if (A.desc_in_lds) {
     const uint4* g = reinterpret_cast<const uint4*>(A.t_desc) + 2 * (size_t)pair * A.max_t;
     uint4* d = const_cast<uint4*>(S.tdesc);
     for (int j = tid; j < 2 * nt; j += M_THREADS) d[j] = g[j];
   }
-  if (MODE == MODE_TRIANG)
+  if (mode_bucketed(MODE))
     for (int i = tid; i < A.max_q; i += M_THREADS) out_match[i] = -1;
   if (tid < HISTO_LENGTH) s_hist[tid] = 0;
   if (tid == 0) s_nm = 0;
-  if constexpr (MODE != MODE_TRIANG) {
+  if constexpr (!mode_bucketed(MODE)) {
     constexpr int NC = GRID_COLS * GRID_ROWS;
     // counts go to start[cell + 2]; after the inclusive scan start[cell + 1] is the
     // cell's first slot, and the fill's atomic increments turn it into the cell's end,
@@ -431,7 +439,8 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     } else {
       const int idx1 = A.q_idx1[qbase + i];
       b0 = A.q_b0[qbase + i]; b1 = A.q_b1[qbase + i];
-      valid = A.q_obs[(size_t)pair * A.max_q + idx1] <= 0;  // no map point yet
+      // TRIANG: the feature has no map point yet; BOW: it has a good one
+      valid = MODE == MODE_TRIANG ? A.q_obs[(size_t)pair * A.max_q + idx1] <= 0 : A.q_obs[(size_t)pair * A.max_q + idx1] > 0;
       qx = A.q_x[qbase + idx1]; qy = A.q_y[qbase + idx1];
       qdesc_ptr = A.q_desc + 32 * (qbase + idx1);
     }
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
 #pragma unroll
         for (int k = 0; k < MK; k++) { c.key[k] = nl[k].x; c.idx[k] = nl[k].y; }
         c.ntot = nt_i & 0x3FFFFFFF;
-        if (MODE == MODE_TRIANG) my_idx1 = A.q_idx1[qbase + i];
+        if (mode_bucketed(MODE)) my_idx1 = A.q_idx1[qbase + i];
       }
       if (base + 64 < nq) fetch(base + 64);
       bool resolved = !active;
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
               found++;
             }
           }
-          const int want = MODE == MODE_MAPPOINTS ? 2 : 1;
+          const int want = (MODE == MODE_MAPPOINTS || MODE == MODE_BOW) ? 2 : 1;
           // c.ntot > MK: candidates beyond the kept ones exist, so the list is not exhaustive
           if (found < want && c.ntot > MK) need_rescan = true;
           if (need_rescan) {
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
             const float4 geo = A.q_geo[qbase + i];
             const uint8_t* qp;
             int b0 = 0, b1 = 0; float qx = 0.f, qy = 0.f;
-            if constexpr (MODE == MODE_TRIANG) {
+            if constexpr (mode_bucketed(MODE)) {
               const int idx1 = A.q_idx1[qbase + i];
               b0 = A.q_b0[qbase + i]; b1 = A.q_b1[qbase + i];
               qx = A.q_x[qbase + idx1]; qy = A.q_y[qbase + idx1];
@@ -536,6 +545,10 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
           } else if constexpr (MODE == MODE_WINDOW) {
             accept = d1 <= A.max_dist;
             occupy = accept;
+          } else if constexpr (MODE == MODE_BOW) {
+            // reference src/ORBmatcher.cc:309-312 resp. :783-785 (d2 = 256 without a second candidate)
+            accept = d1 <= A.max_dist && (float)d1 < A.nnratio * (float)d2;
+            occupy = accept;
           } else {
             accept = true;  // thresholds were applied during the scan
             occupy = true;
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
         bool conflict = false;
         if (!resolved && s1 >= 0) {
           conflict = S.claim[s1] < lane;
-          if (MODE == MODE_MAPPOINTS && s2 >= 0) conflict = conflict || S.claim[s2] < lane;
+          if ((MODE == MODE_MAPPOINTS || MODE == MODE_BOW) && s2 >= 0) conflict = conflict || S.claim[s2] < lane;
         }
         __builtin_amdgcn_wave_barrier();
         if (occupy) S.claim[s1] = 0x7FFFFFFF;
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
             if (occupy) S.occ[s1] = 1;
             atomicAdd(&s_nm, 1);
             A.q_slot[qbase + i] = s1;
-            if constexpr (MODE == MODE_TRIANG) out_match[my_idx1] = s1;
+            if constexpr (mode_bucketed(MODE)) out_match[my_idx1] = s1;
             else atomicMax(&out_match[s1], i);  // a later query overwrites an earlier one
           }
         }
@@ -579,7 +592,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       const int s1 = A.q_slot[qbase + i];
       int b = -1;
       if (s1 >= 0) {
-        const float qa = MODE == MODE_TRIANG ? A.q_angle[qbase + A.q_idx1[qbase + i]] : A.q_angle[(qbase + i) * A.qs];
+        const float qa = mode_bucketed(MODE) ? A.q_angle[qbase + A.q_idx1[qbase + i]] : A.q_angle[(qbase + i) * A.qs];
         b = rot_bin(qa - A.t_angle[(tbase + s1) * A.ts]);
         atomicAdd(&s_hist[b], 1);
       }
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     for (int i = tid; i < nq; i += M_THREADS) {
       const int b = A.q_bin[qbase + i];
       if (b >= 0 && b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) {
-        if (MODE == MODE_TRIANG) out_match[A.q_idx1[qbase + i]] = -1;
+        if (mode_bucketed(MODE)) out_match[A.q_idx1[qbase + i]] = -1;
         else out_match[A.q_slot[qbase + i]] = -2;
         atomicSub(&s_nm, 1);
       }
@@ -805,6 +818,32 @@ int run_match(MatchArgs& A, int n_pairs, DevBuf& buf) {
   int rc = launch_match<MODE>(A, n_pairs, 0);
   if (rc != ORBHIP_OK) return rc;
   ORB_HIP_CHECK(hipDeviceSynchronize());
+  return ORBHIP_OK;
+}
+
+// Merge-walk of two ordered DBoW2 feature vectors (reference src/ORBmatcher.cc:251-352,
+// :730-817, :894-1011): the side-1 features of every common node, in the reference's
+// visiting order, each with the CSR range of its side-2 bucket.
+int bucket_queries(int n1, int n2, int n_nodes1, const int* node1, const int* start1, const int* items1, int n_nodes2,
+                   const int* node2, const int* start2, const int* items2, std::vector<int>& q_idx1,
+                   std::vector<int>& q_b0, std::vector<int>& q_b1) {
+  for (int a = 0, b = 0; a < n_nodes1 && b < n_nodes2;) {
+    if (node1[a] == node2[b]) {
+      for (int p = start1[a]; p < start1[a + 1]; p++) {
+        const int idx1 = items1[p];
+        if (idx1 < 0 || idx1 >= n1) { set_error("feature index out of range"); return ORBHIP_ERR_ARG; }
+        q_idx1.push_back(idx1); q_b0.push_back(start2[b]); q_b1.push_back(start2[b + 1]);
+      }
+      a++; b++;
+    } else if (node1[a] < node2[b]) {
+      a = (int)(std::lower_bound(node1 + a, node1 + n_nodes1, node2[b]) - node1);
+    } else {
+      b = (int)(std::lower_bound(node2 + b, node2 + n_nodes2, node1[a]) - node2);
+    }
+  }
+  const int nitems2 = start2[n_nodes2];
+  for (int p = 0; p < nitems2; p++)
+    if (items2[p] < 0 || items2[p] >= n2) { set_error("feature index out of range"); return ORBHIP_ERR_ARG; }
   return ORBHIP_OK;
 }
 
@@ -1039,28 +1078,14 @@ int orb_search_for_triangulation(int device_id, int n1, const float* x1, const f
       !node1 || !start1 || !items1 || !node2 || !start2 || !items2 || !f12 || !scale_factors2 || !level_sigma2_2) {
     set_error("null argument"); return ORBHIP_ERR_ARG;
   }
-  // merge-walk of the two ordered feature vectors (reference src/ORBmatcher.cc:894-1011):
-  // the queries, in the reference's visiting order, each with its keyframe-2 bucket
   std::vector<int> q_idx1, q_b0, q_b1;
-  for (int a = 0, b = 0; a < n_nodes1 && b < n_nodes2;) {
-    if (node1[a] == node2[b]) {
-      for (int p = start1[a]; p < start1[a + 1]; p++) {
-        const int idx1 = items1[p];
-        if (idx1 < 0 || idx1 >= n1) { set_error("feature index out of range"); return ORBHIP_ERR_ARG; }
-        q_idx1.push_back(idx1); q_b0.push_back(start2[b]); q_b1.push_back(start2[b + 1]);
-      }
-      a++; b++;
-    } else if (node1[a] < node2[b]) {
-      a = (int)(std::lower_bound(node1 + a, node1 + n_nodes1, node2[b]) - node1);
-    } else {
-      b = (int)(std::lower_bound(node2 + b, node2 + n_nodes2, node1[a]) - node2);
-    }
+  {
+    const int rcq = bucket_queries(n1, n2, n_nodes1, node1, start1, items1, n_nodes2, node2, start2, items2, q_idx1, q_b0, q_b1);
+    if (rcq != ORBHIP_OK) return rcq;
   }
   const int nq = (int)q_idx1.size();
   if (nq == 0) return ORBHIP_OK;
   const int nitems2 = start2[n_nodes2];
-  for (int p = 0; p < nitems2; p++)
-    if (items2[p] < 0 || items2[p] >= n2) { set_error("feature index out of range"); return ORBHIP_ERR_ARG; }
   DevSel g(device_id);
   DevBuf buf;
   MatchArgs A{};
@@ -1086,6 +1111,63 @@ int orb_search_for_triangulation(int device_id, int n1, const float* x1, const f
   UP(buf, desc2, (size_t)n2 * 32, A.t_desc); UP(buf, obs2.data(), n2, A.t_obs);
   UP(buf, (const int*)nullptr, max_q, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
   int rc = run_match<MODE_TRIANG>(A, 1, buf);
+  if (rc != ORBHIP_OK) return rc;
+  std::vector<int> m(max_q);
+  ORB_HIP_CHECK(hipMemcpy(m.data(), A.out_match, sizeof(int) * max_q, hipMemcpyDeviceToHost));
+  std::copy(m.begin(), m.begin() + n1, matches12);
+  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_search_by_bow(int device_id, int n1, const float* angle1, const uint8_t* desc1, const uint8_t* ok1, int n2,
+                      const float* angle2, const uint8_t* desc2, const uint8_t* ok2, int n_nodes1, const int* node1,
+                      const int* start1, const int* items1, int n_nodes2, const int* node2, const int* start2,
+                      const int* items2, float nnratio, int max_dist, int check_orientation, int* matches12,
+                      int* n_matches) {
+  if (!n_matches) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  *n_matches = 0;
+  if (n1 <= 0) return ORBHIP_OK;
+  if (!matches12) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n2 <= 0 || n_nodes1 <= 0 || n_nodes2 <= 0) return ORBHIP_OK;
+  if (n2 > 65535) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
+  if (!angle1 || !desc1 || !ok1 || !angle2 || !desc2 || !ok2 || !node1 || !start1 || !items1 || !node2 || !start2 ||
+      !items2) {
+    set_error("null argument"); return ORBHIP_ERR_ARG;
+  }
+  std::vector<int> q_idx1, q_b0, q_b1;
+  {
+    const int rcq = bucket_queries(n1, n2, n_nodes1, node1, start1, items1, n_nodes2, node2, start2, items2, q_idx1, q_b0, q_b1);
+    if (rcq != ORBHIP_OK) return rcq;
+  }
+  const int nq = (int)q_idx1.size();
+  if (nq == 0) return ORBHIP_OK;
+  const int nitems2 = start2[n_nodes2];
+  DevSel g(device_id);
+  DevBuf buf;
+  MatchArgs A{};
+  const int max_q = std::max(nq, n1);  // per-pair slices hold both query-indexed and idx1-indexed arrays
+  A.max_q = max_q; A.max_t = n2; A.nlevels = 1; A.check_ori = check_orientation;
+  A.nnratio = nnratio; A.max_dist = max_dist;
+  // a side-2 feature that may not be matched at all starts out taken
+  std::vector<int> obs1(max_q, 0), obs2(n2), oct2(n2, 0);
+  for (int i = 0; i < n1; i++) obs1[i] = ok1[i] ? 1 : 0;
+  for (int i = 0; i < n2; i++) obs2[i] = ok2[i] ? 0 : 1;
+  std::vector<float> qa(max_q, 0.f);
+  std::vector<uint8_t> qd((size_t)max_q * 32, 0);
+  std::copy(angle1, angle1 + n1, qa.begin());
+  std::copy(desc1, desc1 + (size_t)n1 * 32, qd.begin());
+  q_idx1.resize(max_q, 0); q_b0.resize(max_q, 0); q_b1.resize(max_q, 0);
+  UP(buf, &nq, 1, A.n_q); UP(buf, &n2, 1, A.n_t);
+  UP(buf, obs1.data(), max_q, A.q_obs); UP(buf, qa.data(), max_q, A.q_angle); UP(buf, qd.data(), (size_t)max_q * 32, A.q_desc);
+  A.q_x = A.q_angle; A.q_y = A.q_angle;  // positions play no part in this search
+  UP(buf, q_idx1.data(), max_q, A.q_idx1); UP(buf, q_b0.data(), max_q, A.q_b0); UP(buf, q_b1.data(), max_q, A.q_b1);
+  UP(buf, items2, nitems2, A.items2);
+  UP(buf, angle2, n2, A.t_angle); A.t_x = A.t_angle; A.t_y = A.t_angle;
+  UP(buf, oct2.data(), n2, A.t_oct);
+  UP(buf, desc2, (size_t)n2 * 32, A.t_desc); UP(buf, obs2.data(), n2, A.t_obs);
+  UP(buf, (const int*)nullptr, max_q, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
+  int rc = run_match<MODE_BOW>(A, 1, buf);
   if (rc != ORBHIP_OK) return rc;
   std::vector<int> m(max_q);
   ORB_HIP_CHECK(hipMemcpy(m.data(), A.out_match, sizeof(int) * max_q, hipMemcpyDeviceToHost));

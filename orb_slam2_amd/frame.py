@@ -54,7 +54,7 @@ class MapPoint:
 class Frame:
     """Keypoints, descriptors, pose and map-point slots of one image."""
 
-    def __init__(self, keypoints, descriptors, scale_factors, level_sigma2, K, bounds, Tcw=None):
+    def __init__(self, keypoints, descriptors, scale_factors, level_sigma2, K, bounds, Tcw=None, feat_vec=None):
         """keypoints: structured array with x, y, octave, angle (undistorted = raw: the
         reference's UndistortKeyPoints is the identity for zero distortion, src/Frame.cc:506-510);
         K = (fx, fy, cx, cy); bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
@@ -68,18 +68,15 @@ class Frame:
         self.mnMinX, self.mnMaxX, self.mnMinY, self.mnMaxY = (float(v) for v in bounds)
         self.mTcw = np.eye(4, dtype=np.float32) if Tcw is None else np.asarray(Tcw, np.float32).reshape(4, 4)
         self.mvpMapPoints = [None] * self.N
+        # DBoW2::FeatureVector: vocabulary node id -> feature indices, ordered by node id
+        self.mFeatVec = dict(sorted((feat_vec or {}).items()))
         self.mnScaleLevels = len(self.mvScaleFactors)
         self.mfScaleFactor = float(self.mvScaleFactors[1]) if self.mnScaleLevels > 1 else 1.2
         self.mfLogScaleFactor = np.float32(np.log(np.float32(self.mfScaleFactor)))
 
 
 class KeyFrame(Frame):
-    """Adds what SearchForTriangulation reads: the feature vector (vocabulary node ->
-    feature indices, ordered by node id) and the pose accessors."""
-
-    def __init__(self, *args, feat_vec=None, **kw):
-        super().__init__(*args, **kw)
-        self.mFeatVec = dict(sorted((feat_vec or {}).items()))
+    """Adds the accessors the keyframe searches use (map point list, pose, image bounds)."""
 
     def GetMapPoint(self, idx):
         return self.mvpMapPoints[idx]

@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .frame import KeyFrame
 from ._lib import FrameBounds, check, ptr
 
 
@@ -259,6 +260,41 @@ class ORBmatcher:
         return nm.value
 
     # ---- SearchForTriangulation (:853) ---------------------------------------------
+    def SearchByBoW(self, pKF, other, vpMatches):
+        """Both overloads of the reference (include/ORBmatcher.h): `other` is a Frame
+        (src/ORBmatcher.cc:222-381, vpMatches indexed by the frame's features) or a KeyFrame
+        (:698-841, vpMatches indexed by pKF's features)."""
+        to_frame = not isinstance(other, KeyFrame)
+        mps1 = pKF.GetMapPointMatches()
+        ok1 = np.array([mp is not None and not mp.isBad() for mp in mps1] or [0], np.uint8)
+        if to_frame:
+            ok2 = np.ones(max(other.N, 1), np.uint8)
+            a2 = other.mvKeys["angle"]
+            max_dist = self.TH_LOW
+        else:
+            mps2 = other.GetMapPointMatches()
+            ok2 = np.array([mp is not None and not mp.isBad() for mp in mps2] or [0], np.uint8)
+            a2 = other.mvKeysUn["angle"]
+            max_dist = self.TH_LOW - 1
+        nd1, st1, it1 = _flat_featvec(pKF.mFeatVec)
+        nd2, st2, it2 = _flat_featvec(other.mFeatVec)
+        m12 = np.full(max(pKF.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        check(self._lib.orb_search_by_bow(
+            self.device, pKF.N, ptr(_f32(pKF.mvKeysUn["angle"])), ptr(pKF.mDescriptors), ptr(ok1),
+            other.N, ptr(_f32(a2)), ptr(other.mDescriptors), ptr(ok2),
+            len(nd1), ptr(nd1), ptr(st1), ptr(it1), len(nd2), ptr(nd2), ptr(st2), ptr(it2),
+            float(self.mfNNratio), int(max_dist), int(self.mbCheckOrientation), ptr(m12), C.byref(nm)))
+        vpMatches.clear()
+        if to_frame:
+            vpMatches.extend([None] * other.N)
+            for i1 in range(pKF.N):
+                if m12[i1] >= 0:
+                    vpMatches[m12[i1]] = mps1[i1]
+        else:
+            vpMatches.extend(mps2[m12[i1]] if m12[i1] >= 0 else None for i1 in range(pKF.N))
+        return nm.value
+
     def SearchForTriangulation(self, pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo=False):
         # epipole of KF1's centre in KF2, reference src/ORBmatcher.cc:862-871
         Cw = pKF1.GetCameraCenter()
@@ -267,17 +303,8 @@ class ORBmatcher:
         ex = np.float32(np.float32(np.float32(np.float32(pKF2.fx) * C2[0]) * invz) + np.float32(pKF2.cx))
         ey = np.float32(np.float32(np.float32(np.float32(pKF2.fy) * C2[1]) * invz) + np.float32(pKF2.cy))
 
-        def flat(fv):
-            nodes = np.array(list(fv.keys()), np.int32)
-            start = np.zeros(len(nodes) + 1, np.int32)
-            items = []
-            for k, v in enumerate(fv.values()):
-                items.extend(v)
-                start[k + 1] = len(items)
-            return nodes, start, np.array(items, np.int32) if items else np.zeros(1, np.int32)
-
-        nd1, st1, it1 = flat(pKF1.mFeatVec)
-        nd2, st2, it2 = flat(pKF2.mFeatVec)
+        nd1, st1, it1 = _flat_featvec(pKF1.mFeatVec)
+        nd2, st2, it2 = _flat_featvec(pKF2.mFeatVec)
         k1, k2 = pKF1.mvKeysUn, pKF2.mvKeysUn
         has1 = np.array([mp is not None for mp in pKF1.mvpMapPoints] or [0], np.uint8)
         has2 = np.array([mp is not None for mp in pKF2.mvpMapPoints] or [0], np.uint8)
@@ -296,6 +323,17 @@ class ORBmatcher:
         vMatchedPairs.clear()
         vMatchedPairs.extend((i, int(m12[i])) for i in range(pKF1.N) if m12[i] >= 0)
         return nm.value
+
+
+def _flat_featvec(fv):
+    """DBoW2::FeatureVector (ordered map node id -> feature indices) as sorted node ids + CSR."""
+    nodes = np.array(list(fv.keys()), np.int32)
+    start = np.zeros(len(nodes) + 1, np.int32)
+    items = []
+    for k, v in enumerate(fv.values()):
+        items.extend(v)
+        start[k + 1] = len(items)
+    return nodes, start, np.array(items, np.int32) if items else np.zeros(1, np.int32)
 
 
 def stereo_match(rows, left, right, scale_factors, min_d, max_d, th_dist=75, device=0):

@@ -379,3 +379,82 @@ def test_stereo_random_crowded(oracle):
         wn, wbi, wbd = oracle.stereo_match(rows, dict(x=lk["x"], y=lk["y"], octave=lk["octave"], desc=ld),
                                            dict(x=rk["x"], y=rk["y"], octave=rk["octave"], desc=rd), sf, 0.0, 300.0, 75)
         assert n == wn and np.array_equal(bi, wbi) and np.array_equal(bd, wbd)
+
+
+def _bow_scene(rng, n1, n2, nnodes=50, dup=True):
+    sf, s2 = scale_tables()
+    rows, cols = 480, 752
+    x2, y2, o2, a2, d2 = random_frame_arrays(rng, n2, rows, cols)
+    src = rng.integers(0, n2, n1)
+    x1, y1, o1 = x2[src].copy(), y2[src].copy(), o2[src].copy()
+    a1 = ((a2[src] + rng.normal(0, 8, n1)) % 360).astype(np.float32)
+    d1 = flip_bits(rng, d2[src], 60)
+    if dup:  # several side-1 features want the same side-2 feature; exact ties in a bucket
+        d2[1::7] = d2[0::7][:len(d2[1::7])]
+    node_of2 = rng.integers(0, nnodes, n2)
+    node_of1 = np.where(rng.uniform(0, 1, n1) < 0.85, node_of2[src], rng.integers(0, nnodes + 5, n1))
+    fv1 = {int(k) * 2: [int(i) for i in np.nonzero(node_of1 == k)[0]] for k in np.unique(node_of1)}
+    fv2 = {int(k) * 2: [int(i) for i in np.nonzero(node_of2 == k)[0]] for k in np.unique(node_of2)}
+    K = (np.float32(500), np.float32(500), np.float32(376), np.float32(240))
+    b = (0, cols, 0, rows)
+    return (kp_struct(x1, y1, o1, a1), d1, fv1), (kp_struct(x2, y2, o2, a2), d2, fv2), (sf, s2, K, b)
+
+
+def _flat(fv):
+    nodes = np.array(list(fv.keys()), np.int32); start = [0]; items = []
+    for v in fv.values():
+        items.extend(v); start.append(len(items))
+    return dict(node=nodes, start=np.array(start, np.int32), items=np.array(items if items else [0], np.int32))
+
+
+@pytest.mark.parametrize("seed,n1,n2,ratio,ori,nnodes", [(0, 800, 900, 0.7, True, 50), (1, 2000, 2000, 0.9, True, 12),
+                                                          (2, 1500, 1200, 0.75, False, 200), (3, 300, 2500, 0.9, True, 3)])
+def test_search_by_bow_both_overloads(oracle, seed, n1, n2, ratio, ori, nnodes):
+    from orb_slam2_amd import Frame, KeyFrame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(seed)
+    (k1, d1, fv1), (k2, d2, fv2), (sf, s2, K, b) = _bow_scene(rng, n1, n2, nnodes)
+    kf1 = KeyFrame(k1, d1, sf, s2, K, b, feat_vec=fv1)
+    has1 = rng.uniform(0, 1, n1) < 0.7
+    bad1 = rng.uniform(0, 1, n1) < 0.05
+    for i in np.nonzero(has1)[0]:
+        kf1.mvpMapPoints[i] = MapPoint(np.zeros(3), d1[i])
+        kf1.mvpMapPoints[i]._bad = bool(bad1[i])
+    ok1 = (has1 & ~bad1).astype(np.uint8)
+    m = ORBmatcher(ratio, ori)
+    # overload 1: keyframe against a frame
+    fr = Frame(k2, d2, sf, s2, K, b, feat_vec=fv2)
+    out = []
+    got = m.SearchByBoW(kf1, fr, out)
+    wn, w12 = oracle.search_by_bow(dict(angle=k1["angle"], desc=d1, ok=ok1), dict(angle=k2["angle"], desc=d2, ok=np.ones(n2, np.uint8)),
+                                   _flat(kf1.mFeatVec), _flat(fr.mFeatVec), ratio, 50, ori)
+    assert got == wn and wn > 30 and len(out) == n2
+    want = [None] * n2
+    for i1 in range(n1):
+        if w12[i1] >= 0:
+            want[w12[i1]] = kf1.mvpMapPoints[i1]
+    assert all(a is w for a, w in zip(out, want))
+    # overload 2: keyframe against keyframe
+    kf2 = KeyFrame(k2, d2, sf, s2, K, b, feat_vec=fv2)
+    has2 = rng.uniform(0, 1, n2) < 0.8
+    for i in np.nonzero(has2)[0]:
+        kf2.mvpMapPoints[i] = MapPoint(np.zeros(3), d2[i])
+    out12 = []
+    got = m.SearchByBoW(kf1, kf2, out12)
+    wn, w12 = oracle.search_by_bow(dict(angle=k1["angle"], desc=d1, ok=ok1), dict(angle=k2["angle"], desc=d2, ok=has2.astype(np.uint8)),
+                                   _flat(kf1.mFeatVec), _flat(kf2.mFeatVec), ratio, 49, ori)
+    assert got == wn and wn > 20 and len(out12) == n1
+    assert all((a is None and w < 0) or (w >= 0 and a is kf2.mvpMapPoints[w]) for a, w in zip(out12, w12))
+
+
+def test_search_by_bow_edge_cases(oracle):
+    from orb_slam2_amd import Frame, KeyFrame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(8)
+    (k1, d1, fv1), (k2, d2, fv2), (sf, s2, K, b) = _bow_scene(rng, 50, 60, 5)
+    kf1 = KeyFrame(k1, d1, sf, s2, K, b, feat_vec=fv1)
+    out = ["x"]
+    assert ORBmatcher(0.7, True).SearchByBoW(kf1, Frame(k2, d2, sf, s2, K, b, feat_vec=fv2), out) == 0  # no map points
+    assert out == [None] * 60
+    for i in range(50):
+        kf1.mvpMapPoints[i] = MapPoint(np.zeros(3), d1[i])
+    assert ORBmatcher(0.7, True).SearchByBoW(kf1, Frame(k2, d2, sf, s2, K, b, feat_vec={}), out) == 0     # no common node
+    assert ORBmatcher(0.7, True).SearchByBoW(kf1, Frame(k2[:0], d2[:0], sf, s2, K, b), out) == 0 and out == []
