@@ -218,6 +218,22 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
                        const float* q_angle, const uint8_t* q_desc, int max_dist,
                        int check_orientation, int* t_match, int* n_matches);
 
+/* The candidate scan of ORBmatcher::Fuse (both overloads, src/ORBmatcher.cc:1133-1175,
+ * :1302-1329) and of the two directions of ORBmatcher::SearchBySim3 (:1479-1506,
+ * :1560-1586): per query GetFeaturesInArea(u, v, radius), the level test
+ * kpLevel < q_level - 1 || kpLevel > q_level -> skip, optionally (chi2 > 0; the first Fuse
+ * overload passes 5.99 and mvInvLevelSigma2) the reprojection gate
+ * e2 * inv_level_sigma2[kpLevel] > chi2 -> skip, and the first minimum of the descriptor
+ * distance.  Queries do not interact; what the callers do with the result (threshold
+ * TH_LOW / TH_HIGH, Replace / AddObservation, the agreement check) stays on the host.
+ * best_idx[i] = -1 and best_dist[i] = INT_MAX when no candidate is left. */
+int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x,
+                    const float* t_y, const int* t_octave, const uint8_t* t_desc,
+                    const float* inv_level_sigma2, int nlevels, double chi2, int n_q,
+                    const uint8_t* q_active, const float* q_u, const float* q_v,
+                    const float* q_radius, const int* q_level, const uint8_t* q_desc,
+                    int* best_idx, int* best_dist);
+
 /* ORBmatcher::SearchByBoW, both overloads:
  *   SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches)
  *     (src/ORBmatcher.cc:222-381; accepts bestDist1 <= TH_LOW: pass max_dist = TH_LOW), and

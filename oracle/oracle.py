@@ -265,6 +265,24 @@ def match_windowed(bounds, train, queries, max_dist, check_ori):
     return n, match[:len(t_x)].copy()
 
 
+def window_best(bounds, train, queries, inv_level_sigma2=None, chi2=0.0):
+    """train: dict(x, y, octave, desc); queries: dict(active, u, v, r, level, desc).
+    Returns (best_idx, best_dist); no candidate -> (-1, INT_MAX)."""
+    t_x, t_y, t_o, t_d = _f32(train["x"]), _f32(train["y"]), _i32(train["octave"]), _u8(train["desc"])
+    q_a, q_u, q_v, q_r = _u8(queries["active"]), _f32(queries["u"]), _f32(queries["v"]), _f32(queries["r"])
+    q_l, q_d = _i32(queries["level"]), _u8(queries["desc"])
+    nq = len(q_a)
+    bi, bd = np.empty(max(nq, 1), np.int32), np.empty(max(nq, 1), np.int32)
+    inv = _f32(inv_level_sigma2) if inv_level_sigma2 is not None else np.ones(16, np.float32)
+    f = C.c_float
+    L = lib()
+    L.orc_window_best.restype = None
+    L.orc_window_best(f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]), C.c_int(len(t_x)), _p(t_x), _p(t_y), _p(t_o),
+                      _p(t_d), _p(inv), C.c_double(chi2), C.c_int(nq), _p(q_a), _p(q_u), _p(q_v), _p(q_r), _p(q_l), _p(q_d),
+                      _p(bi), _p(bd))
+    return bi[:nq].copy(), bd[:nq].copy()
+
+
 def stereo_match(rows, left, right, scale_factors, min_d, max_d, th_dist=75):
     """left / right: dicts with x, y, octave, desc.  Returns (n, best_idx, best_dist)."""
     L = lib()

@@ -1057,6 +1057,41 @@ ORC_API int orc_stereo_match(int rows, int n_left, const float* l_x, const float
   return nmatches;
 }
 
+/* The candidate scan shared by ORBmatcher::Fuse (both overloads, ORBmatcher.cc:1133-1175,
+ * :1302-1329) and SearchBySim3 (:1479-1506, :1560-1586): GetFeaturesInArea(u, v, radius)
+ * without a level range, then per candidate the level test
+ * kpLevel < n - 1 || kpLevel > n -> skip (q_level = n), in the first Fuse overload also the
+ * reprojection gate e2 * mvInvLevelSigma2[kpLevel] > 5.99 -> skip (:1158-1164; chi2 > 0
+ * turns it on), and the first minimum of the descriptor distance.  Queries are independent.
+ * best_idx[i] = -1 / best_dist[i] = INT_MAX when no candidate is left. */
+ORC_API void orc_window_best(float minX, float maxX, float minY, float maxY, int nt, const float* t_x, const float* t_y,
+                             const int* t_oct, const uint8_t* t_desc, const float* inv_level_sigma2, double chi2, int nq,
+                             const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_r,
+                             const int* q_level, const uint8_t* q_desc, int* best_idx, int* best_dist) {
+  OrcGrid g;
+  grid_build(&g, nt, t_x, t_y, t_oct, minX, maxX, minY, maxY);
+  int* cand = (int*)malloc(sizeof(int) * (nt + 1));
+  for (int i = 0; i < nq; i++) {
+    best_idx[i] = -1; best_dist[i] = 0x7FFFFFFF;
+    if (!q_active[i]) continue;
+    const int nc = grid_query(&g, q_u[i], q_v[i], q_r[i], 0, -1, cand);
+    for (int k = 0; k < nc; k++) {
+      const int idx = cand[k];
+      const int kpLevel = t_oct[idx];
+      if (kpLevel < q_level[i] - 1 || kpLevel > q_level[i]) continue;
+      if (chi2 > 0) {
+        const float ex = q_u[i] - t_x[idx], ey = q_v[i] - t_y[idx];
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * inv_level_sigma2[kpLevel] > chi2) continue;
+      }
+      const int dist = orc_descriptor_distance(q_desc + 32 * (size_t)i, t_desc + 32 * (size_t)idx);
+      if (dist < best_dist[i]) { best_dist[i] = dist; best_idx[i] = idx; }
+    }
+  }
+  free(cand);
+  grid_free(&g);
+}
+
 /* CheckDistEpipolarLine (ORBmatcher.cc:180-207) */
 static int check_dist_epipolar(float x1, float y1, float x2, float y2, const float* F12, float sigma2_kp2) {
   const float a = x1 * F12[0] + y1 * F12[3] + F12[6];

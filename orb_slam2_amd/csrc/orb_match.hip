@@ -152,10 +152,12 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, co
 // ---------------------------------------------------------------------------
 constexpr int MK = 4;  // ranked candidates kept per query
 constexpr int M_THREADS = 1024;
-enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2, MODE_WINDOW = 3, MODE_BOW = 4 };
+enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2, MODE_WINDOW = 3, MODE_BOW = 4, MODE_BEST = 5 };
 // TRIANG and BOW take their candidates from vocabulary-node buckets instead of the grid and
 // index the output by the feature of side 1
 constexpr bool mode_bucketed(int mode) { return mode == MODE_TRIANG || mode == MODE_BOW; }
+// the output is indexed by the query instead of the train keypoint
+constexpr bool mode_out_by_query(int mode) { return mode_bucketed(mode) || mode == MODE_BEST; }
 
 struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
@@ -171,7 +173,9 @@ struct MatchArgs {
   const int* q_obs; const float* q_xw; const uint8_t* q_desc; const int* q_oct; const float* q_angle;
   const float* q_x; const float* q_y; const float* q_viewcos; const uint8_t* q_track;
   const float* q_r; const int* q_minl; const int* q_maxl;  // WINDOW: radius and level range per query
-  int max_dist;                                            // WINDOW: accept threshold
+  int max_dist;                                            // WINDOW / BOW: accept threshold
+  double chi2;                                             // BEST: reprojection gate (0 = off), with sigma2[] = inverse level sigma2
+  int* out_dist;                                           // BEST: distance of the best candidate per query
   const int* q_idx1; const int* q_b0; const int* q_b1; const int* items2;  // TRIANG buckets
   const float* tcw;
   float fx, fy, cx, cy;
@@ -256,6 +260,13 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
         if (!(fabsf(S.kx[j] - x) < r && fabsf(S.ky[j] - y) < r)) continue;
         const int mypos = pos++;
         if (S.occ[j]) continue;
+        if constexpr (MODE == MODE_BEST) {
+          if (A.chi2 > 0) {  // reference src/ORBmatcher.cc:1158-1164
+            const float ex = x - S.kx[j], ey = y - S.ky[j];
+            const float e2 = ex * ex + ey * ey;
+            if ((double)(e2 * A.sigma2[min((int)S.koct[j], kMaxLevels - 1)]) > A.chi2) continue;
+          }
+        }
         const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
         cand_insert(c, ((uint32_t)d << 20) | (uint32_t)mypos, (uint32_t)j);
       }
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     }
   }
   const size_t tbase = (size_t)pair * A.max_t, qbase = (size_t)pair * A.max_q;
-  int* out_match = A.out_match + (mode_bucketed(MODE) ? qbase : tbase);
+  int* out_match = A.out_match + (mode_out_by_query(MODE) ? qbase : tbase);
 
   // ---- phase 0: train keypoints to LDS; 64x48 grid as CSR in insertion order
   // (Frame::AssignFeaturesToGrid / PosInGrid, reference src/Frame.cc:190-213, 461-477)
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     S.koct[j] = (unsigned char)min(max(A.t_oct[(tbase + j) * A.ts], 0), 255);
     S.occ[j] = (unsigned char)(A.t_obs[tbase + j] > 0);
     S.claim[j] = 0x7FFFFFFF;
-    if (!mode_bucketed(MODE)) out_match[j] = -1;
+    if (!mode_out_by_query(MODE)) out_match[j] = -1;
   }
   if (A.desc_in_lds) {
     const uint4* g = reinterpret_cast<const uint4*>(A.t_desc) + 2 * (size_t)pair * A.max_t;
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       geo.x = A.q_x[qbase + i]; geo.y = A.q_y[qbase + i]; geo.z = r * A.sf[lvl];
       geo.w = __int_as_float(((lvl - 1 + 1024) & 0xFFFF) | ((lvl + 1024) << 16));
       qdesc_ptr = A.q_desc + 32 * (qbase + i);
-    } else if constexpr (MODE == MODE_WINDOW) {
+    } else if constexpr (MODE == MODE_WINDOW || MODE == MODE_BEST) {
       valid = A.q_track[qbase + i] != 0;
       const int lo = min(max(A.q_minl[qbase + i], -1000), 1000), hi = min(max(A.q_maxl[qbase + i], -1000), 1000);
       geo.x = A.q_x[qbase + i]; geo.y = A.q_y[qbase + i]; geo.z = A.q_r[qbase + i];
@@ -451,6 +462,13 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       const uint32_t qd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
       scan_query<MODE>(A, S, pair, nt, geo, qd, b0, b1, qx, qy, c);
     }
+    if constexpr (MODE == MODE_BEST) {
+      // independent queries: the first minimum is the result
+      const bool any = c.key[0] != 0xFFFFFFFFu;
+      A.out_match[qbase + i] = any ? (int)c.idx[0] : -1;
+      A.out_dist[qbase + i] = any ? (int)(c.key[0] >> 20) : 0x7FFFFFFF;
+      continue;
+    }
     A.q_geo[qbase + i] = geo;
     int obs_bit = 0;
     if (MODE == MODE_FRAMES || MODE == MODE_MAPPOINTS) obs_bit = A.q_obs[qbase + i] > 0 ? 0x40000000 : 0;
@@ -460,6 +478,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     A.q_slot[qbase + i] = -1;
   }
   __syncthreads();
+  if constexpr (MODE == MODE_BEST) return;
 
   // ---- phase B: replay the reference's query order, 64 queries per step
   if (tid < 64) {
@@ -1055,6 +1074,48 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
   if (rc != ORBHIP_OK) return rc;
   ORB_HIP_CHECK(hipMemcpy(t_match, A.out_match, sizeof(int) * n_t, hipMemcpyDeviceToHost));
   ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
+                    const int* t_octave, const uint8_t* t_desc, const float* inv_level_sigma2, int nlevels, double chi2,
+                    int n_q, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_radius,
+                    const int* q_level, const uint8_t* q_desc, int* best_idx, int* best_dist) {
+  if (n_q <= 0) return ORBHIP_OK;
+  if (!best_idx || !best_dist) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  for (int i = 0; i < n_q; i++) { best_idx[i] = -1; best_dist[i] = 0x7FFFFFFF; }
+  if (n_t <= 0) return ORBHIP_OK;
+  if (n_t > 65535) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
+  if (!t_x || !t_y || !t_octave || !t_desc || !q_active || !q_u || !q_v || !q_radius || !q_level || !q_desc) {
+    set_error("null argument"); return ORBHIP_ERR_ARG;
+  }
+  if (chi2 > 0 && (!inv_level_sigma2 || nlevels < 1 || nlevels > kMaxLevels)) { set_error("level table out of range"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  DevBuf buf;
+  MatchArgs A{};
+  A.max_q = n_q; A.max_t = n_t; A.nlevels = 1; A.b = bounds; A.chi2 = chi2 > 0 ? chi2 : 0.0;
+  if (chi2 > 0) {
+    for (int i = 0; i < kMaxLevels; i++) A.sigma2[i] = inv_level_sigma2[std::min(i, nlevels - 1)];
+    for (int i = 0; i < n_t; i++)
+      if (t_octave[i] < 0 || t_octave[i] >= nlevels) { set_error("octave out of range"); return ORBHIP_ERR_ARG; }
+  }
+  // the level test of the callers, kpLevel < n - 1 || kpLevel > n -> skip, as a level range
+  std::vector<int> lo(n_q), hi(n_q), free_slots(n_t, -1);
+  for (int i = 0; i < n_q; i++) { hi[i] = std::max(q_level[i], 0); lo[i] = q_level[i] - 1; }
+  for (int i = 0; i < n_q; i++)
+    if (q_level[i] < 0) { set_error("negative level"); return ORBHIP_ERR_ARG; }
+  UP(buf, &n_q, 1, A.n_q); UP(buf, &n_t, 1, A.n_t);
+  UP(buf, q_active, n_q, A.q_track); UP(buf, q_u, n_q, A.q_x); UP(buf, q_v, n_q, A.q_y); UP(buf, q_radius, n_q, A.q_r);
+  UP(buf, lo.data(), n_q, A.q_minl); UP(buf, hi.data(), n_q, A.q_maxl); UP(buf, q_desc, (size_t)n_q * 32, A.q_desc);
+  UP(buf, t_x, n_t, A.t_x); UP(buf, t_y, n_t, A.t_y); UP(buf, t_octave, n_t, A.t_oct);
+  UP(buf, t_desc, (size_t)n_t * 32, A.t_desc); UP(buf, free_slots.data(), n_t, A.t_obs);
+  A.q_angle = A.q_x; A.t_angle = A.t_x;
+  UP(buf, (const int*)nullptr, n_q, A.out_match); UP(buf, (const int*)nullptr, n_q, A.out_dist);
+  UP(buf, (const int*)nullptr, 1, A.n_matches);
+  int rc = run_match<MODE_BEST>(A, 1, buf);
+  if (rc != ORBHIP_OK) return rc;
+  ORB_HIP_CHECK(hipMemcpy(best_idx, A.out_match, sizeof(int) * n_q, hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpy(best_dist, A.out_dist, sizeof(int) * n_q, hipMemcpyDeviceToHost));
   return ORBHIP_OK;
 }
 

@@ -10,6 +10,8 @@ class MapPoint:
         self._desc = np.asarray(descriptor, np.uint8).reshape(32)
         self._nobs = int(observations)
         self._bad = False
+        self.mObservations = {}  # keyframe -> feature index (reference include/MapPoint.h)
+        self.mpReplaced = None
         # filled by Frame::isInFrustum in the reference (src/Frame.cc:343-355)
         self.mbNeedTrackInView = False
         self.mnTrackedScaleLevel = 0
@@ -25,6 +27,33 @@ class MapPoint:
 
     def Observations(self):
         return self._nobs
+
+    # observation bookkeeping used by Fuse / SearchBySim3 (reference src/MapPoint.cc:137-175,
+    # 276-334, 471-492); the monocular subset: one observation counts once
+    def AddObservation(self, pKF, idx):
+        if pKF in self.mObservations:
+            return
+        self.mObservations[pKF] = int(idx)
+        self._nobs += 1
+
+    def IsInKeyFrame(self, pKF):
+        return pKF in self.mObservations
+
+    def GetIndexInKeyFrame(self, pKF):
+        return self.mObservations.get(pKF, -1)
+
+    def Replace(self, pMP):
+        if pMP is self:
+            return
+        obs, self.mObservations = self.mObservations, {}
+        self._bad = True
+        self.mpReplaced = pMP
+        for pKF, idx in obs.items():
+            if not pMP.IsInKeyFrame(pKF):
+                pKF.ReplaceMapPointMatch(idx, pMP)
+                pMP.AddObservation(pKF, idx)
+            else:
+                pKF.EraseMapPointMatch(idx)
 
     def isBad(self):
         return self._bad
@@ -83,6 +112,23 @@ class KeyFrame(Frame):
 
     def GetMapPointMatches(self):
         return list(self.mvpMapPoints)
+
+    def GetMapPoints(self):
+        """reference src/KeyFrame.cc: the set of map points that are not bad"""
+        return {mp for mp in self.mvpMapPoints if mp is not None and not mp.isBad()}
+
+    def AddMapPoint(self, pMP, idx):
+        self.mvpMapPoints[idx] = pMP
+
+    def ReplaceMapPointMatch(self, idx, pMP):
+        self.mvpMapPoints[idx] = pMP
+
+    def EraseMapPointMatch(self, idx):
+        self.mvpMapPoints[idx] = None
+
+    @property
+    def mvInvLevelSigma2(self):
+        return (np.float32(1.0) / self.mvLevelSigma2).astype(np.float32)
 
     def IsInImage(self, x, y):
         return self.mnMinX <= x < self.mnMaxX and self.mnMinY <= y < self.mnMaxY

@@ -295,6 +295,162 @@ class ORBmatcher:
             vpMatches.extend(mps2[m12[i1]] if m12[i1] >= 0 else None for i1 in range(pKF.N))
         return nm.value
 
+    # ---- Fuse / SearchBySim3: independent best-candidate scans + the reference's host logic ----
+    def _window_best(self, KF, q, inv_sigma2=None, chi2=0.0):
+        k = KF.mvKeysUn
+        nq = len(q["active"])
+        bi = np.full(max(nq, 1), -1, np.int32)
+        bd = np.zeros(max(nq, 1), np.int32)
+        inv = _f32(inv_sigma2) if inv_sigma2 is not None else np.ones(1, np.float32)
+        b = FrameBounds(KF.mnMinX, KF.mnMaxX, KF.mnMinY, KF.mnMaxY)
+        check(self._lib.orb_window_best(
+            self.device, b, KF.N, ptr(_f32(k["x"])), ptr(_f32(k["y"])), ptr(_i32(k["octave"])), ptr(KF.mDescriptors),
+            ptr(inv), len(inv), float(chi2), nq, ptr(_u8(q["active"])), ptr(_f32(q["u"])), ptr(_f32(q["v"])),
+            ptr(_f32(q["r"])), ptr(_i32(q["minl"])), ptr(_u8(q["desc"])), ptr(bi), ptr(bd)))
+        return bi, bd
+
+    @staticmethod
+    def _project_for_fuse(pKF, Rcw, tcw, Ow, pMP, th, q, i, camera_dist=None):
+        """Gates of reference src/ORBmatcher.cc:1089-1131 (= :1255-1299; SearchBySim3 :1438-1476
+        measures the distance in the camera frame and has no viewing-angle gate): fills query i,
+        returns False if the point is rejected before the candidate scan."""
+        f32 = np.float32
+        p3Dw = pMP.GetWorldPos()
+        p3Dc = _mat3_mul_add(Rcw, p3Dw, tcw) if camera_dist is None else camera_dist
+        if p3Dc[2] < 0.0:
+            return False
+        invz = f32(1.0 / np.float64(p3Dc[2])) if p3Dc[2] != 0 else f32(np.inf)
+        u = f32(f32(f32(pKF.fx) * f32(p3Dc[0] * invz)) + f32(pKF.cx))
+        v = f32(f32(f32(pKF.fy) * f32(p3Dc[1] * invz)) + f32(pKF.cy))
+        if not pKF.IsInImage(u, v):
+            return False
+        if camera_dist is None:
+            PO = (p3Dw - Ow).astype(f32)
+        else:
+            PO = p3Dc
+        dist3D = f32(np.sqrt(np.float64(PO[0]) ** 2 + np.float64(PO[1]) ** 2 + np.float64(PO[2]) ** 2))  # cv::norm
+        if dist3D < pMP.GetMinDistanceInvariance() or dist3D > pMP.GetMaxDistanceInvariance():
+            return False
+        if camera_dist is None:
+            Pn = pMP.GetNormal()
+            if np.float64(f32(f32(f32(PO[0] * Pn[0]) + f32(PO[1] * Pn[1])) + f32(PO[2] * Pn[2]))) < 0.5 * np.float64(dist3D):
+                return False
+        n = pMP.PredictScale(dist3D, pKF)
+        q["active"][i] = 1
+        q["u"][i], q["v"][i] = u, v
+        q["r"][i] = f32(f32(th) * pKF.mvScaleFactors[n])
+        q["minl"][i] = n  # the predicted level; candidates of level n - 1 and n pass
+        q["desc"][i] = pMP.GetDescriptor()
+        return True
+
+    def Fuse(self, pKF, *args):
+        """Both overloads (include/ORBmatcher.h): Fuse(pKF, vpMapPoints, th=3.0) and
+        Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)."""
+        if len(args) >= 2 and isinstance(args[0], np.ndarray):
+            return self._fuse_sim3(pKF, *args)
+        return self._fuse(pKF, *args)
+
+    def _fuse(self, pKF, vpMapPoints, th=3.0):
+        # reference src/ORBmatcher.cc:1060-1205.  The scan of a point does not depend on what
+        # earlier points did to the map; the gates that do (isBad, IsInKeyFrame) are evaluated
+        # again in the loop below, in the reference's order.
+        Rcw, tcw, Ow = pKF.GetRotation(), pKF.GetTranslation(), pKF.GetCameraCenter()
+        n = len(vpMapPoints)
+        q = self._blank_queries(n)
+        for i, pMP in enumerate(vpMapPoints):
+            if pMP is not None:
+                self._project_for_fuse(pKF, Rcw, tcw, Ow, pMP, th, q, i)
+        bi, bd = self._window_best(pKF, q, pKF.mvInvLevelSigma2, 5.99)
+        nFused = 0
+        for i, pMP in enumerate(vpMapPoints):
+            if pMP is None or pMP.isBad() or pMP.IsInKeyFrame(pKF) or not q["active"][i]:
+                continue
+            if bi[i] >= 0 and bd[i] <= self.TH_LOW:
+                pMPinKF = pKF.GetMapPoint(int(bi[i]))
+                if pMPinKF is not None:
+                    if not pMPinKF.isBad():
+                        if pMPinKF.Observations() > pMP.Observations():
+                            pMP.Replace(pMPinKF)
+                        else:
+                            pMPinKF.Replace(pMP)
+                else:
+                    pMP.AddObservation(pKF, int(bi[i]))
+                    pKF.AddMapPoint(pMP, int(bi[i]))
+                nFused += 1
+        return nFused
+
+    def _fuse_sim3(self, pKF, Scw, vpPoints, th, vpReplacePoint):
+        # reference src/ORBmatcher.cc:1218-1354
+        f32 = np.float32
+        Scw = np.asarray(Scw, f32).reshape(4, 4)
+        sRcw = Scw[:3, :3]
+        scw = f32(np.sqrt(np.float64(f32(f32(sRcw[0, 0] * sRcw[0, 0]) + f32(sRcw[0, 1] * sRcw[0, 1])) + f32(sRcw[0, 2] * sRcw[0, 2]))))
+        Rcw = (sRcw / scw).astype(f32)
+        tcw = (Scw[:3, 3] / scw).astype(f32)
+        Ow = (-(Rcw.T @ tcw)).astype(f32)
+        spAlreadyFound = pKF.GetMapPoints()
+        q = self._blank_queries(len(vpPoints))
+        for i, pMP in enumerate(vpPoints):
+            if not pMP.isBad() and pMP not in spAlreadyFound:
+                self._project_for_fuse(pKF, Rcw, tcw, Ow, pMP, th, q, i)
+        bi, bd = self._window_best(pKF, q)
+        nFused = 0
+        for i, pMP in enumerate(vpPoints):
+            if pMP.isBad() or pMP in spAlreadyFound or not q["active"][i]:
+                continue
+            if bi[i] >= 0 and bd[i] <= self.TH_LOW:
+                pMPinKF = pKF.GetMapPoint(int(bi[i]))
+                if pMPinKF is not None:
+                    if not pMPinKF.isBad():
+                        vpReplacePoint[i] = pMPinKF
+                else:
+                    pMP.AddObservation(pKF, int(bi[i]))
+                    pKF.AddMapPoint(pMP, int(bi[i]))
+                nFused += 1
+        return nFused
+
+    def SearchBySim3(self, pKF1, pKF2, vpMatches12, s12, R12, t12, th):
+        # reference src/ORBmatcher.cc:1368-1615
+        f32 = np.float32
+        R1w, t1w = pKF1.GetRotation(), pKF1.GetTranslation()
+        R2w, t2w = pKF2.GetRotation(), pKF2.GetTranslation()
+        R12 = np.asarray(R12, f32).reshape(3, 3)
+        t12 = np.asarray(t12, f32).reshape(3)
+        sR12 = (f32(s12) * R12).astype(f32)
+        sR21 = (np.float64(1.0) / np.float64(f32(s12)) * R12.T.astype(np.float64)).astype(f32)
+        t21 = (-_mat3_mul_add(sR21, t12, np.zeros(3, f32))).astype(f32)
+        mps1, mps2 = pKF1.GetMapPointMatches(), pKF2.GetMapPointMatches()
+        N1, N2 = len(mps1), len(mps2)
+        done1, done2 = [False] * N1, [False] * N2
+        for i in range(N1):
+            pMP = vpMatches12[i]
+            if pMP is not None:
+                done1[i] = True
+                idx2 = pMP.GetIndexInKeyFrame(pKF2)
+                if 0 <= idx2 < N2:
+                    done2[idx2] = True
+
+        def one_way(mps, done, Rw, tw, sR, t, dst):
+            q = self._blank_queries(len(mps))
+            for i, pMP in enumerate(mps):
+                if pMP is None or done[i] or pMP.isBad():
+                    continue
+                pc = _mat3_mul_add(Rw, pMP.GetWorldPos(), tw)
+                pd = _mat3_mul_add(sR, pc, t)
+                self._project_for_fuse(dst, None, None, None, pMP, th, q, i, camera_dist=pd)
+            bi, bd = self._window_best(dst, q)
+            return [int(bi[i]) if q["active"][i] and bi[i] >= 0 and bd[i] <= self.TH_HIGH else -1 for i in range(len(mps))]
+
+        vnMatch1 = one_way(mps1, done1, R1w, t1w, sR21, t21, pKF2)
+        vnMatch2 = one_way(mps2, done2, R2w, t2w, sR12, t12, pKF1)
+        nFound = 0
+        for i1 in range(N1):
+            idx2 = vnMatch1[i1]
+            if idx2 >= 0 and vnMatch2[idx2] == i1:
+                vpMatches12[i1] = mps2[idx2]
+                nFound += 1
+        return nFound
+
     def SearchForTriangulation(self, pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo=False):
         # epipole of KF1's centre in KF2, reference src/ORBmatcher.cc:862-871
         Cw = pKF1.GetCameraCenter()

@@ -458,3 +458,191 @@ def test_search_by_bow_edge_cases(oracle):
         kf1.mvpMapPoints[i] = MapPoint(np.zeros(3), d1[i])
     assert ORBmatcher(0.7, True).SearchByBoW(kf1, Frame(k2, d2, sf, s2, K, b, feat_vec={}), out) == 0     # no common node
     assert ORBmatcher(0.7, True).SearchByBoW(kf1, Frame(k2[:0], d2[:0], sf, s2, K, b), out) == 0 and out == []
+
+
+def _fuse_scene(rng, n_kp=1500, n_mp=900, rows=480, cols=752):
+    """A keyframe at the origin and map points that project near its keypoints (several per
+    keypoint now and then, so that Replace / AddMapPoint of one point matters to a later one)."""
+    from orb_slam2_amd import KeyFrame, MapPoint
+    sf, s2 = scale_tables()
+    K = (np.float32(500), np.float32(500), np.float32(376), np.float32(240))
+    x, y, o, a, d = random_frame_arrays(rng, n_kp, rows, cols)
+    kf = KeyFrame(kp_struct(x, y, o, a), d, sf, s2, K, (0.0, float(cols), 0.0, float(rows)), np.eye(4, dtype=np.float32))
+    for i in range(0, n_kp, 3):
+        mp = MapPoint(np.zeros(3), d[i], observations=int(rng.integers(1, 6)))
+        mp.mObservations[kf] = i
+        kf.mvpMapPoints[i] = mp
+    pts = []
+    src = rng.integers(0, n_kp, n_mp)
+    src[1::5] = src[0::5][:len(src[1::5])]  # duplicates: two points aim at the same keypoint
+    for j in src:
+        Z = np.float32(rng.uniform(3, 20))
+        du, dv = rng.normal(0, 1.2, 2)
+        Xc = np.array([(x[j] + du - K[2]) / K[0] * Z, (y[j] + dv - K[3]) / K[1] * Z, Z], np.float32)
+        mp = MapPoint(Xc, flip_bits(rng, d[j:j + 1], 70)[0], observations=int(rng.integers(1, 6)))
+        mp.mfMaxDistance = float(np.linalg.norm(Xc) * sf[o[j]] * rng.uniform(0.95, 1.05))
+        mp.mfMinDistance = mp.mfMaxDistance / float(sf[7])
+        mp.mNormalVector = (Xc / np.linalg.norm(Xc)).astype(np.float32)
+        pts.append(mp)
+    pts[5] = None
+    pts[7]._bad = True
+    return kf, pts
+
+
+def test_fuse_against_sequential_restatement(oracle):
+    """ORBmatcher::Fuse(pKF, vpMapPoints, th): the GPU scan of all points at once plus the host
+    loop must leave the map in the state a point-by-point evaluation with the oracle's scan does."""
+    import copy
+    from orb_slam2_amd import ORBmatcher
+    rng = np.random.default_rng(31)
+    kf, pts = _fuse_scene(rng)
+    kf_b, pts_b = copy.deepcopy((kf, pts))
+    m = ORBmatcher(0.8, True)
+    got = m.Fuse(kf, pts, 3.0)
+    # sequential restatement on the copy (reference src/ORBmatcher.cc:1078-1202)
+    k = kf_b.mvKeysUn
+    train = dict(x=k["x"], y=k["y"], octave=k["octave"], desc=kf_b.mDescriptors)
+    bounds = (kf_b.mnMinX, kf_b.mnMaxX, kf_b.mnMinY, kf_b.mnMaxY)
+    want = 0
+    for pMP in pts_b:
+        if pMP is None or pMP.isBad() or pMP.IsInKeyFrame(kf_b):
+            continue
+        q = m._blank_queries(1)
+        if not m._project_for_fuse(kf_b, kf_b.GetRotation(), kf_b.GetTranslation(), kf_b.GetCameraCenter(), pMP, 3.0, q, 0):
+            continue
+        bi, bd = oracle.window_best(bounds, train, dict(active=q["active"], u=q["u"], v=q["v"], r=q["r"], level=q["minl"],
+                                                        desc=q["desc"]), kf_b.mvInvLevelSigma2, 5.99)
+        if bi[0] >= 0 and bd[0] <= 50:
+            other = kf_b.GetMapPoint(int(bi[0]))
+            if other is not None:
+                if not other.isBad():
+                    if other.Observations() > pMP.Observations():
+                        pMP.Replace(other)
+                    else:
+                        other.Replace(pMP)
+            else:
+                pMP.AddObservation(kf_b, int(bi[0]))
+                kf_b.AddMapPoint(pMP, int(bi[0]))
+            want += 1
+    assert got == want and want > 200
+    ida = {id(p): j for j, p in enumerate(pts) if p is not None}
+    idb = {id(p): j for j, p in enumerate(pts_b) if p is not None}
+    slot_a = [ida.get(id(p), -2 if p is not None else -1) for p in kf.mvpMapPoints]
+    slot_b = [idb.get(id(p), -2 if p is not None else -1) for p in kf_b.mvpMapPoints]
+    assert slot_a == slot_b
+    assert [p is not None and p.isBad() for p in pts] == [p is not None and p.isBad() for p in pts_b]
+
+
+def test_fuse_sim3_and_search_by_sim3(oracle):
+    from orb_slam2_amd import KeyFrame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(32)
+    kf, pts = _fuse_scene(rng, 1200, 700)
+    pts = [p for p in pts if p is not None]
+    m = ORBmatcher(0.8, True)
+    S = np.eye(4, dtype=np.float32); S[:3, :3] *= np.float32(1.5)  # scale is divided out again
+    for p in pts:
+        p._pos = (p._pos / np.float32(1.5)).astype(np.float32)
+        p.mfMaxDistance /= 1.5; p.mfMinDistance /= 1.5
+    repl = [None] * len(pts)
+    before = list(kf.mvpMapPoints)
+    got = m.Fuse(kf, S, pts, 4.0, repl)
+    k = kf.mvKeysUn
+    train = dict(x=k["x"], y=k["y"], octave=k["octave"], desc=kf.mDescriptors)
+    bounds = (kf.mnMinX, kf.mnMaxX, kf.mnMinY, kf.mnMaxY)
+    want, wrepl, wadd = 0, [None] * len(pts), {}
+    cur = list(before)
+    Rcw = np.eye(3, dtype=np.float32); tcw = np.zeros(3, np.float32)
+    for i, p in enumerate(pts):
+        if p.isBad():
+            continue
+        q = m._blank_queries(1)
+        if not m._project_for_fuse(kf, Rcw, tcw, np.zeros(3, np.float32), p, 4.0, q, 0):
+            continue
+        bi, bd = oracle.window_best(bounds, train, dict(active=q["active"], u=q["u"], v=q["v"], r=q["r"], level=q["minl"], desc=q["desc"]))
+        if bi[0] >= 0 and bd[0] <= 50:
+            if cur[bi[0]] is not None:
+                if not cur[bi[0]].isBad():
+                    wrepl[i] = cur[bi[0]]
+            else:
+                cur[bi[0]] = p
+            want += 1
+    assert got == want and want > 150
+    assert all(a is b for a, b in zip(repl, wrepl)) and all(a is b for a, b in zip(kf.mvpMapPoints, cur))
+
+    # SearchBySim3: two keyframes seeing the same points, identity relative transform
+    sf, s2 = scale_tables()
+    K = (np.float32(500), np.float32(500), np.float32(376), np.float32(240))
+    n = 900
+    x, y, o, a, d = random_frame_arrays(rng, n, 480, 752)
+    kf1 = KeyFrame(kp_struct(x, y, o, a), d, sf, s2, K, (0.0, 752.0, 0.0, 480.0), np.eye(4, dtype=np.float32))
+    perm = rng.permutation(n)
+    kf2 = KeyFrame(kp_struct(x[perm] + rng.normal(0, 0.5, n).astype(np.float32), y[perm], o[perm], a[perm]), flip_bits(rng, d[perm], 30),
+                   sf, s2, K, (0.0, 752.0, 0.0, 480.0), np.eye(4, dtype=np.float32))
+    for i in range(n):
+        for kfx, idx in ((kf1, i), (kf2, int(np.nonzero(perm == i)[0][0]))):
+            if rng.uniform() < 0.7:
+                Z = np.float32(rng.uniform(3, 20))
+                kk = kfx.mvKeysUn[idx]
+                Xc = np.array([(kk["x"] - K[2]) / K[0] * Z, (kk["y"] - K[3]) / K[1] * Z, Z], np.float32)
+                mp = MapPoint(Xc, kfx.mDescriptors[idx])
+                mp.mfMaxDistance = float(np.linalg.norm(Xc) * sf[kk["octave"]] * rng.uniform(0.95, 1.05))
+                mp.mfMinDistance = mp.mfMaxDistance / float(sf[7])
+                mp.mObservations[kfx] = idx
+                kfx.mvpMapPoints[idx] = mp
+    v12 = [None] * n
+    for i in range(0, n, 11):
+        j = int(np.nonzero(perm == i)[0][0])
+        if kf2.mvpMapPoints[j] is not None:
+            v12[i] = kf2.mvpMapPoints[j]
+    pre = list(v12)
+    got = m.SearchBySim3(kf1, kf2, v12, 1.0, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 7.5)
+
+    def one_way(src, dst, done):
+        kd = dst.mvKeysUn
+        tr = dict(x=kd["x"], y=kd["y"], octave=kd["octave"], desc=dst.mDescriptors)
+        out = [-1] * src.N
+        for i, p in enumerate(src.mvpMapPoints):
+            if p is None or done[i] or p.isBad():
+                continue
+            q = m._blank_queries(1)
+            pc = p.GetWorldPos()
+            if not m._project_for_fuse(dst, None, None, None, p, 7.5, q, 0, camera_dist=pc):
+                continue
+            bi, bd = oracle.window_best((0.0, 752.0, 0.0, 480.0), tr, dict(active=q["active"], u=q["u"], v=q["v"], r=q["r"],
+                                                                           level=q["minl"], desc=q["desc"]))
+            if bi[0] >= 0 and bd[0] <= 100:
+                out[i] = int(bi[0])
+        return out
+    done1 = [p is not None for p in pre]
+    done2 = [False] * n
+    for p in pre:
+        if p is not None:
+            done2[p.GetIndexInKeyFrame(kf2)] = True
+    m1, m2 = one_way(kf1, kf2, done1), one_way(kf2, kf1, done2)
+    want = sum(1 for i in range(n) if m1[i] >= 0 and m2[m1[i]] == i)
+    assert got == want and want > 100
+    for i in range(n):
+        if m1[i] >= 0 and m2[m1[i]] == i:
+            assert v12[i] is kf2.mvpMapPoints[m1[i]]
+        else:
+            assert v12[i] is pre[i]
+
+
+def test_window_best_raw(oracle):
+    """orb_window_best through the C ABI against the oracle, crowded windows and the chi2 gate."""
+    from orb_slam2_amd._lib import FrameBounds, check, lib, ptr
+    rng = np.random.default_rng(33)
+    train, q, bounds = _windowed_case(rng, 2500, 3000)
+    sf, s2 = scale_tables()
+    inv = (np.float32(1) / s2).astype(np.float32)
+    lvl = np.clip(q["maxl"], 0, 7).astype(np.int32)
+    for chi2 in (0.0, 5.99):
+        wbi, wbd = oracle.window_best(bounds, train, dict(active=q["active"], u=q["u"], v=q["v"], r=q["r"], level=lvl, desc=q["desc"]), inv, chi2)
+        nq = len(lvl)
+        bi, bd = np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+        f = lambda a, t: np.ascontiguousarray(a, t)
+        t = [f(train["x"], "f4"), f(train["y"], "f4"), f(train["octave"], "i4"), f(train["desc"], "u1")]
+        qa = [f(q["active"], "u1"), f(q["u"], "f4"), f(q["v"], "f4"), f(q["r"], "f4"), lvl, f(q["desc"], "u1")]
+        check(lib().orb_window_best(0, FrameBounds(*bounds), len(t[0]), *[ptr(a) for a in t], ptr(inv), 8, chi2, nq,
+                                    *[ptr(a) for a in qa], ptr(bi), ptr(bd)))
+        assert np.array_equal(bi, wbi) and np.array_equal(bd, wbd) and (bi >= 0).sum() > 500
