@@ -218,6 +218,22 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
                        const float* q_angle, const uint8_t* q_desc, int max_dist,
                        int check_orientation, int* t_match, int* n_matches);
 
+/* ORBmatcher::SearchForInitialization(const Frame& F1, const Frame& F2,
+ * vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize)
+ * (src/ORBmatcher.cc:543-686).  Per F1 feature of octave 0: the level-0 features of F2
+ * within windowSize of (prev_x, prev_y), best and second-best distance over those whose
+ * recorded match distance is larger (:596), accepted if best <= TH_LOW and
+ * best < second * nnratio; an accepted match takes the F2 feature away from the F1 feature
+ * that held it (:619-623); rotation check over every accepted query (:653-677).
+ * matches12[i1] = i2 or -1.  Updating vbPrevMatched (:681-683) is left to the caller. */
+int orb_search_for_initialization(int device_id, OrbFrameBounds bounds, int n1,
+                                  const int* octave1, const float* angle1, const uint8_t* desc1,
+                                  const float* prev_x, const float* prev_y, int n2,
+                                  const float* x2, const float* y2, const int* octave2,
+                                  const float* angle2, const uint8_t* desc2, float window_size,
+                                  float nnratio, int check_orientation, int* matches12,
+                                  int* n_matches);
+
 /* The candidate scan of ORBmatcher::Fuse (both overloads, src/ORBmatcher.cc:1133-1175,
  * :1302-1329) and of the two directions of ORBmatcher::SearchBySim3 (:1479-1506,
  * :1560-1586): per query GetFeaturesInArea(u, v, radius), the level test

@@ -265,6 +265,23 @@ def match_windowed(bounds, train, queries, max_dist, check_ori):
     return n, match[:len(t_x)].copy()
 
 
+def search_for_initialization(bounds, f1, prev, f2, window, nnratio, check_ori=True):
+    """f1: dict(octave, angle, desc); prev: (n1, 2) previous positions; f2: dict(x, y, octave, angle, desc)."""
+    o1, a1, d1 = _i32(f1["octave"]), _f32(f1["angle"]), _u8(f1["desc"])
+    prev = np.asarray(prev, np.float32).reshape(-1, 2)
+    px, py = _f32(prev[:, 0]), _f32(prev[:, 1])
+    x2, y2, o2, a2, d2 = _f32(f2["x"]), _f32(f2["y"]), _i32(f2["octave"]), _f32(f2["angle"]), _u8(f2["desc"])
+    n1, n2 = len(o1), len(x2)
+    m12 = np.full(max(n1, 1), -1, np.int32)
+    f = C.c_float
+    L = lib()
+    L.orc_search_for_initialization.restype = C.c_int
+    n = L.orc_search_for_initialization(f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]), C.c_int(n1), _p(o1), _p(a1), _p(d1),
+                                        _p(px), _p(py), C.c_int(n2), _p(x2), _p(y2), _p(o2), _p(a2), _p(d2), f(window),
+                                        f(nnratio), C.c_int(int(check_ori)), _p(m12))
+    return n, m12[:n1].copy()
+
+
 def window_best(bounds, train, queries, inv_level_sigma2=None, chi2=0.0):
     """train: dict(x, y, octave, desc); queries: dict(active, u, v, r, level, desc).
     Returns (best_idx, best_dist); no candidate -> (-1, INT_MAX)."""

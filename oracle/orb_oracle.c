@@ -1057,6 +1057,63 @@ ORC_API int orc_stereo_match(int rows, int n_left, const float* l_x, const float
   return nmatches;
 }
 
+/* ORBmatcher::SearchForInitialization (ORBmatcher.cc:543-686) on flat arrays; prev_x/prev_y
+ * = vbPrevMatched (not updated here: :681-683 is the caller's). */
+ORC_API int orc_search_for_initialization(float minX, float maxX, float minY, float maxY, int n1, const int* oct1,
+                                          const float* ang1, const uint8_t* desc1, const float* prev_x, const float* prev_y,
+                                          int n2, const float* x2, const float* y2, const int* oct2, const float* ang2,
+                                          const uint8_t* desc2, float windowSize, float nnratio, int check_ori,
+                                          int* vnMatches12) {
+  int nmatches = 0;
+  OrcGrid g;
+  grid_build(&g, n2, x2, y2, oct2, minX, maxX, minY, maxY);
+  int* cand = (int*)malloc(sizeof(int) * (n2 + 1));
+  int* vMatchedDistance = (int*)malloc(sizeof(int) * (n2 + 1));
+  int* vnMatches21 = (int*)malloc(sizeof(int) * (n2 + 1));
+  int* hist_items = (int*)malloc(sizeof(int) * (n1 + 1));
+  int* hist_bin = (int*)malloc(sizeof(int) * (n1 + 1));
+  int nhist = 0;
+  for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+  for (int i = 0; i < n2; i++) { vMatchedDistance[i] = 0x7FFFFFFF; vnMatches21[i] = -1; }
+  for (int i1 = 0; i1 < n1; i1++) {
+    const int level1 = oct1[i1];
+    if (level1 > 0) continue;
+    const int nc = grid_query(&g, prev_x[i1], prev_y[i1], windowSize, level1, level1, cand);
+    if (nc == 0) continue;
+    int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx2 = -1;
+    for (int k = 0; k < nc; k++) {
+      const int i2 = cand[k];
+      const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_ori) { hist_items[nhist] = i1; hist_bin[nhist] = rot_bin(ang1[i1] - ang2[bestIdx2]); nhist++; }
+      }
+    }
+  }
+  if (check_ori) {
+    int sizes[HISTO_LENGTH] = {0}, i1, i2, i3;
+    for (int k = 0; k < nhist; k++) sizes[hist_bin[k]]++;
+    orc_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+    for (int k = 0; k < nhist; k++) {
+      const int b = hist_bin[k];
+      if (b == i1 || b == i2 || b == i3) continue;
+      if (vnMatches12[hist_items[k]] >= 0) { vnMatches12[hist_items[k]] = -1; nmatches--; }
+    }
+  }
+  free(cand); free(vMatchedDistance); free(vnMatches21); free(hist_items); free(hist_bin);
+  grid_free(&g);
+  return nmatches;
+}
+
 /* The candidate scan shared by ORBmatcher::Fuse (both overloads, ORBmatcher.cc:1133-1175,
  * :1302-1329) and SearchBySim3 (:1479-1506, :1560-1586): GetFeaturesInArea(u, v, radius)
  * without a level range, then per candidate the level test

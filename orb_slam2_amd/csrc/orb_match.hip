@@ -152,12 +152,12 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, co
 // ---------------------------------------------------------------------------
 constexpr int MK = 4;  // ranked candidates kept per query
 constexpr int M_THREADS = 1024;
-enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2, MODE_WINDOW = 3, MODE_BOW = 4, MODE_BEST = 5 };
+enum { MODE_FRAMES = 0, MODE_MAPPOINTS = 1, MODE_TRIANG = 2, MODE_WINDOW = 3, MODE_BOW = 4, MODE_BEST = 5, MODE_INIT = 6 };
 // TRIANG and BOW take their candidates from vocabulary-node buckets instead of the grid and
 // index the output by the feature of side 1
 constexpr bool mode_bucketed(int mode) { return mode == MODE_TRIANG || mode == MODE_BOW; }
 // the output is indexed by the query instead of the train keypoint
-constexpr bool mode_out_by_query(int mode) { return mode_bucketed(mode) || mode == MODE_BEST; }
+constexpr bool mode_out_by_query(int mode) { return mode_bucketed(mode) || mode == MODE_BEST || mode == MODE_INIT; }
 
 struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
@@ -218,6 +218,7 @@ struct MatchShared {
   unsigned char* occ;    // max_t: train keypoint can no longer be taken
   int* claim;            // max_t: lowest pending lane that wants to take the keypoint
   const uint4* tdesc;    // train descriptors, two uint4 each (LDS copy if it fits, else global)
+  int* owner;            // INIT: query that currently holds the train keypoint, -1 = none
   uint2* lists;          // max_q * MK ranked candidates (LDS if it fits, else global scratch)
   int* ntot;             // max_q: candidates seen (bit 30: the query's map point has observations), -1 = inactive
 };
@@ -259,7 +260,7 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
         }
         if (!(fabsf(S.kx[j] - x) < r && fabsf(S.ky[j] - y) < r)) continue;
         const int mypos = pos++;
-        if (S.occ[j]) continue;
+        if (MODE != MODE_INIT && S.occ[j]) continue;
         if constexpr (MODE == MODE_BEST) {
           if (A.chi2 > 0) {  // reference src/ORBmatcher.cc:1158-1164
             const float ex = x - S.kx[j], ey = y - S.ky[j];
@@ -268,6 +269,11 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
           }
         }
         const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+        if constexpr (MODE == MODE_INIT) {
+          // occ = matched distance + 1 (0 = never matched): skip if vMatchedDistance[i2] <= dist
+          // (reference src/ORBmatcher.cc:596)
+          if (S.occ[j] && (int)S.occ[j] - 1 <= d) continue;
+        }
         cand_insert(c, ((uint32_t)d << 20) | (uint32_t)mypos, (uint32_t)j);
       }
     }
@@ -329,6 +335,8 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     S.koct = p; p += (A.max_t + 3) & ~3;
     S.occ = p; p += (A.max_t + 3) & ~3;
     S.claim = reinterpret_cast<int*>(p); p += sizeof(int) * A.max_t;
+    S.owner = reinterpret_cast<int*>(p);
+    if (MODE == MODE_INIT) p += sizeof(int) * A.max_t;
     p = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
     if (A.desc_in_lds) {
       S.tdesc = reinterpret_cast<const uint4*>(p); p += 32 * (size_t)A.max_t;
@@ -352,6 +360,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     S.kx[j] = A.t_x[(tbase + j) * A.ts]; S.ky[j] = A.t_y[(tbase + j) * A.ts];
     S.koct[j] = (unsigned char)min(max(A.t_oct[(tbase + j) * A.ts], 0), 255);
     S.occ[j] = (unsigned char)(A.t_obs[tbase + j] > 0);
+    if (MODE == MODE_INIT) S.owner[j] = -1;
     S.claim[j] = 0x7FFFFFFF;
     if (!mode_out_by_query(MODE)) out_match[j] = -1;
   }
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     uint4* d = const_cast<uint4*>(S.tdesc);
     for (int j = tid; j < 2 * nt; j += M_THREADS) d[j] = g[j];
   }
-  if (mode_bucketed(MODE))
+  if (mode_bucketed(MODE) || MODE == MODE_INIT)
     for (int i = tid; i < A.max_q; i += M_THREADS) out_match[i] = -1;
   if (tid < HISTO_LENGTH) s_hist[tid] = 0;
   if (tid == 0) s_nm = 0;
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       geo.x = A.q_x[qbase + i]; geo.y = A.q_y[qbase + i]; geo.z = r * A.sf[lvl];
       geo.w = __int_as_float(((lvl - 1 + 1024) & 0xFFFF) | ((lvl + 1024) << 16));
       qdesc_ptr = A.q_desc + 32 * (qbase + i);
-    } else if constexpr (MODE == MODE_WINDOW || MODE == MODE_BEST) {
+    } else if constexpr (MODE == MODE_WINDOW || MODE == MODE_BEST || MODE == MODE_INIT) {
       valid = A.q_track[qbase + i] != 0;
       const int lo = min(max(A.q_minl[qbase + i], -1000), 1000), hi = min(max(A.q_maxl[qbase + i], -1000), 1000);
       geo.x = A.q_x[qbase + i]; geo.y = A.q_y[qbase + i]; geo.z = A.q_r[qbase + i];
@@ -518,13 +527,15 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
           int found = 0;
 #pragma unroll
           for (int k = 0; k < MK; k++) {
-            if (c.key[k] != 0xFFFFFFFFu && !S.occ[c.idx[k]]) {
+            const int o_k = c.key[k] != 0xFFFFFFFFu ? (int)S.occ[c.idx[k]] : 1;
+            const bool avail_k = MODE == MODE_INIT ? (o_k == 0 || o_k - 1 > (int)(c.key[k] >> 20)) : o_k == 0;
+            if (c.key[k] != 0xFFFFFFFFu && avail_k) {
               if (found == 0) { s1 = (int)c.idx[k]; d1 = (int)(c.key[k] >> 20); }
               else if (found == 1) { s2 = (int)c.idx[k]; d2 = (int)(c.key[k] >> 20); }
               found++;
             }
           }
-          const int want = (MODE == MODE_MAPPOINTS || MODE == MODE_BOW) ? 2 : 1;
+          const int want = (MODE == MODE_MAPPOINTS || MODE == MODE_BOW || MODE == MODE_INIT) ? 2 : 1;
           // c.ntot > MK: candidates beyond the kept ones exist, so the list is not exhaustive
           if (found < want && c.ntot > MK) need_rescan = true;
           if (need_rescan) {
@@ -564,6 +575,10 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
           } else if constexpr (MODE == MODE_WINDOW) {
             accept = d1 <= A.max_dist;
             occupy = accept;
+          } else if constexpr (MODE == MODE_INIT) {
+            // reference src/ORBmatcher.cc:613-616 (bestDist2 = INT_MAX without a second candidate)
+            accept = d1 <= TH_LOW && (float)d1 < (float)(s2 >= 0 ? d2 : 0x7FFFFFFF) * A.nnratio;
+            occupy = accept;
           } else if constexpr (MODE == MODE_BOW) {
             // reference src/ORBmatcher.cc:309-312 resp. :783-785 (d2 = 256 without a second candidate)
             accept = d1 <= A.max_dist && (float)d1 < A.nnratio * (float)d2;
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
         bool conflict = false;
         if (!resolved && s1 >= 0) {
           conflict = S.claim[s1] < lane;
-          if ((MODE == MODE_MAPPOINTS || MODE == MODE_BOW) && s2 >= 0) conflict = conflict || S.claim[s2] < lane;
+          if ((MODE == MODE_MAPPOINTS || MODE == MODE_BOW || MODE == MODE_INIT) && s2 >= 0) conflict = conflict || S.claim[s2] < lane;
         }
         __builtin_amdgcn_wave_barrier();
         if (occupy) S.claim[s1] = 0x7FFFFFFF;
@@ -591,11 +606,25 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
         if (!resolved && lane < first_conf) {
           resolved = true;
           if (accept) {
-            if (occupy) S.occ[s1] = 1;
+            if constexpr (MODE == MODE_INIT) {
+              // a keypoint matched before goes to the new query (reference :619-628)
+              const int prev = S.owner[s1];
+              if (prev >= 0) { out_match[prev] = -1; atomicSub(&s_nm, 1); }
+              S.owner[s1] = i;
+              S.occ[s1] = (unsigned char)(d1 + 1);
+              out_match[i] = s1;
+            } else if (occupy) {
+              S.occ[s1] = 1;
+            }
             atomicAdd(&s_nm, 1);
             A.q_slot[qbase + i] = s1;
-            if constexpr (mode_bucketed(MODE)) out_match[my_idx1] = s1;
-            else atomicMax(&out_match[s1], i);  // a later query overwrites an earlier one
+            if constexpr (MODE == MODE_INIT) {
+              // stored above
+            } else if constexpr (mode_bucketed(MODE)) {
+              out_match[my_idx1] = s1;
+            } else {
+              atomicMax(&out_match[s1], i);  // a later query overwrites an earlier one
+            }
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -634,9 +663,15 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     for (int i = tid; i < nq; i += M_THREADS) {
       const int b = A.q_bin[qbase + i];
       if (b >= 0 && b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) {
-        if (mode_bucketed(MODE)) out_match[A.q_idx1[qbase + i]] = -1;
-        else out_match[A.q_slot[qbase + i]] = -2;
-        atomicSub(&s_nm, 1);
+        if constexpr (MODE == MODE_INIT) {
+          // the histogram holds every accepted query; one whose keypoint was taken over
+          // later is no longer a match (reference src/ORBmatcher.cc:668-673)
+          if (out_match[i] >= 0) { out_match[i] = -1; atomicSub(&s_nm, 1); }
+        } else {
+          if (mode_bucketed(MODE)) out_match[A.q_idx1[qbase + i]] = -1;
+          else out_match[A.q_slot[qbase + i]] = -2;
+          atomicSub(&s_nm, 1);
+        }
       }
     }
     __syncthreads();
@@ -644,12 +679,13 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   if (tid == 0) A.n_matches[pair] = s_nm;
 }
 
-size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds, bool desc_in_lds) {
+size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds, bool desc_in_lds, bool owner = false) {
   size_t n = sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + 2 * sizeof(float) * (size_t)max_t +
              sizeof(unsigned short) * (size_t)((max_t + 1) & ~1) + 2 * (size_t)((max_t + 3) & ~3) +
              sizeof(int) * (size_t)max_t + 32;
   if (lists_in_lds) n += (sizeof(uint2) * MK + sizeof(int)) * (size_t)max_q;
   if (desc_in_lds) n += 32 * (size_t)max_t;
+  if (owner) n += sizeof(int) * (size_t)max_t;
   return n;
 }
 
@@ -809,9 +845,10 @@ int launch_match(const MatchArgs& A0, int n_pairs, hipStream_t st) {
   MatchArgs A = A0;
   constexpr size_t kLdsLimit = 156 * 1024;
   // descriptors first (every candidate reads them), then the ranked lists if there is room
-  A.desc_in_lds = match_lds_bytes(A.max_t, A.max_q, false, true) <= kLdsLimit;
-  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, A.desc_in_lds != 0) <= kLdsLimit;
-  const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0);
+  constexpr bool own = MODE == MODE_INIT;
+  A.desc_in_lds = match_lds_bytes(A.max_t, A.max_q, false, true, own) <= kLdsLimit;
+  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, A.desc_in_lds != 0, own) <= kLdsLimit;
+  const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0, own);
   if (lds > kLdsLimit) { set_error("too many train keypoints for the LDS-resident grid (limit about 9000)"); return ORBHIP_ERR_UNSUPPORTED; }
   static bool raised[64] = {};  // per device: raise the function's dynamic LDS limit once
   int dev = 0;
@@ -1116,6 +1153,45 @@ int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* 
   if (rc != ORBHIP_OK) return rc;
   ORB_HIP_CHECK(hipMemcpy(best_idx, A.out_match, sizeof(int) * n_q, hipMemcpyDeviceToHost));
   ORB_HIP_CHECK(hipMemcpy(best_dist, A.out_dist, sizeof(int) * n_q, hipMemcpyDeviceToHost));
+  return ORBHIP_OK;
+}
+
+int orb_search_for_initialization(int device_id, OrbFrameBounds bounds, int n1, const int* octave1, const float* angle1,
+                                  const uint8_t* desc1, const float* prev_x, const float* prev_y, int n2,
+                                  const float* x2, const float* y2, const int* octave2, const float* angle2,
+                                  const uint8_t* desc2, float window_size, float nnratio, int check_orientation,
+                                  int* matches12, int* n_matches) {
+  if (!n_matches) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  *n_matches = 0;
+  if (n1 <= 0) return ORBHIP_OK;
+  if (!matches12) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n2 <= 0) return ORBHIP_OK;
+  if (n2 > 65535) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
+  if (!octave1 || !angle1 || !desc1 || !prev_x || !prev_y || !x2 || !y2 || !octave2 || !angle2 || !desc2) {
+    set_error("null argument"); return ORBHIP_ERR_ARG;
+  }
+  DevSel g(device_id);
+  DevBuf buf;
+  MatchArgs A{};
+  A.max_q = n1; A.max_t = n2; A.nlevels = 1; A.check_ori = check_orientation; A.b = bounds; A.nnratio = nnratio;
+  // only features of the original image are matched (level1 > 0 -> continue, reference :569),
+  // against level 0 of the other frame (GetFeaturesInArea(..., level1, level1), :575)
+  std::vector<uint8_t> act(n1);
+  std::vector<float> r(n1, window_size);
+  std::vector<int> zero(std::max(n1, n2), 0), free_slots(n2, -1);
+  for (int i = 0; i < n1; i++) act[i] = octave1[i] > 0 ? 0 : 1;
+  UP(buf, &n1, 1, A.n_q); UP(buf, &n2, 1, A.n_t);
+  UP(buf, act.data(), n1, A.q_track); UP(buf, prev_x, n1, A.q_x); UP(buf, prev_y, n1, A.q_y); UP(buf, r.data(), n1, A.q_r);
+  UP(buf, zero.data(), n1, A.q_minl); A.q_maxl = A.q_minl;
+  UP(buf, desc1, (size_t)n1 * 32, A.q_desc); UP(buf, angle1, n1, A.q_angle);
+  UP(buf, x2, n2, A.t_x); UP(buf, y2, n2, A.t_y); UP(buf, octave2, n2, A.t_oct); UP(buf, angle2, n2, A.t_angle);
+  UP(buf, desc2, (size_t)n2 * 32, A.t_desc); UP(buf, free_slots.data(), n2, A.t_obs);
+  UP(buf, (const int*)nullptr, n1, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
+  int rc = run_match<MODE_INIT>(A, 1, buf);
+  if (rc != ORBHIP_OK) return rc;
+  ORB_HIP_CHECK(hipMemcpy(matches12, A.out_match, sizeof(int) * n1, hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
   return ORBHIP_OK;
 }
 

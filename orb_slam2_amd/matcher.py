@@ -260,6 +260,27 @@ class ORBmatcher:
         return nm.value
 
     # ---- SearchForTriangulation (:853) ---------------------------------------------
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, vnMatches12, windowSize=10):
+        """reference src/ORBmatcher.cc:543-686.  vbPrevMatched: (N1, 2) float32 array of the
+        previously matched positions, updated in place (:681-683); vnMatches12: list, replaced."""
+        prev = np.asarray(vbPrevMatched, np.float32)
+        k1, k2 = F1.mvKeysUn, F2.mvKeysUn
+        m12 = np.full(max(F1.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        b = FrameBounds(F2.mnMinX, F2.mnMaxX, F2.mnMinY, F2.mnMaxY)
+        check(self._lib.orb_search_for_initialization(
+            self.device, b, F1.N, ptr(_i32(k1["octave"])), ptr(_f32(k1["angle"])), ptr(F1.mDescriptors),
+            ptr(_f32(prev[:, 0])), ptr(_f32(prev[:, 1])), F2.N, ptr(_f32(k2["x"])), ptr(_f32(k2["y"])),
+            ptr(_i32(k2["octave"])), ptr(_f32(k2["angle"])), ptr(F2.mDescriptors), float(windowSize),
+            float(self.mfNNratio), int(self.mbCheckOrientation), ptr(m12), C.byref(nm)))
+        vnMatches12.clear()
+        vnMatches12.extend(int(v) for v in m12[:F1.N])
+        for i1 in range(F1.N):
+            if m12[i1] >= 0:
+                vbPrevMatched[i1, 0] = k2["x"][m12[i1]]
+                vbPrevMatched[i1, 1] = k2["y"][m12[i1]]
+        return nm.value
+
     def SearchByBoW(self, pKF, other, vpMatches):
         """Both overloads of the reference (include/ORBmatcher.h): `other` is a Frame
         (src/ORBmatcher.cc:222-381, vpMatches indexed by the frame's features) or a KeyFrame

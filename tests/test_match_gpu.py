@@ -646,3 +646,36 @@ def test_window_best_raw(oracle):
         check(lib().orb_window_best(0, FrameBounds(*bounds), len(t[0]), *[ptr(a) for a in t], ptr(inv), 8, chi2, nq,
                                     *[ptr(a) for a in qa], ptr(bi), ptr(bd)))
         assert np.array_equal(bi, wbi) and np.array_equal(bd, wbd) and (bi >= 0).sum() > 500
+
+
+@pytest.mark.parametrize("seed,n,win,ratio,ori", [(0, 1500, 100, 0.9, True), (1, 2500, 40, 0.8, True), (2, 800, 100, 0.95, False),
+                                                   (3, 2000, 250, 0.9, True)])
+def test_search_for_initialization(oracle, seed, n, win, ratio, ori):
+    """Level-0 window search with match stealing and the matched-distance table: near-duplicate
+    descriptors in F1 make several features compete for the same F2 feature."""
+    from orb_slam2_amd import Frame, ORBmatcher
+    rng = np.random.default_rng(seed)
+    sf, s2 = scale_tables()
+    rows, cols = 480, 752
+    K = (np.float32(500), np.float32(500), np.float32(376), np.float32(240))
+    b = (0.0, float(cols), 0.0, float(rows))
+    x2, y2, o2, a2, d2 = random_frame_arrays(rng, n, rows, cols)
+    o2[rng.uniform(0, 1, n) < 0.6] = 0
+    src = rng.integers(0, n, n)
+    src[1::4] = src[0::4][:len(src[1::4])]            # competing features
+    x1 = (x2[src] + rng.normal(0, 8, n)).astype(np.float32)
+    y1 = (y2[src] + rng.normal(0, 8, n)).astype(np.float32)
+    o1 = o2[src].copy()
+    a1 = ((a2[src] + rng.normal(0, 8, n)) % 360).astype(np.float32)
+    d1 = flip_bits(rng, d2[src], 50)
+    F1 = Frame(kp_struct(x1, y1, o1, a1), d1, sf, s2, K, b)
+    F2 = Frame(kp_struct(x2, y2, o2, a2), d2, sf, s2, K, b)
+    prev = np.stack([x1, y1], 1).astype(np.float32)
+    prev0 = prev.copy()
+    out = []
+    got = ORBmatcher(ratio, ori).SearchForInitialization(F1, F2, prev, out, win)
+    wn, w12 = oracle.search_for_initialization(b, dict(octave=o1, angle=a1, desc=d1), prev0,
+                                               dict(x=x2, y=y2, octave=o2, angle=a2, desc=d2), win, ratio, ori)
+    assert got == wn and wn > 100 and np.array_equal(np.array(out, np.int32), w12)
+    hit = w12 >= 0
+    assert np.array_equal(prev[hit, 0], x2[w12[hit]]) and np.array_equal(prev[~hit], prev0[~hit])
