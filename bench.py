@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
     ap.add_argument("--knn", type=int, default=1000000, help="queries = database rows of the kNN-2 leg (0 = skip)")
-    ap.add_argument("--cpu-frames", type=int, default=60, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -231,6 +231,14 @@ def main():
         tc = time.perf_counter() - tc0
         cpu = {"value": round(n / tc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames of the same sequence: oracle extraction + SearchByProjection on consecutive pairs" % n}
+        if knn is not None:
+            # the oracle's sequential kNN-2 on a slice of the same descriptors, reported per second of one core
+            sq, sdb = q[:2000], db[:100000]
+            tq0 = time.perf_counter()
+            O.knn2_bruteforce(sq, sdb, 0.7)
+            tq = time.perf_counter() - tq0
+            knn["cpu_baseline"] = {"pairs_per_s": round(len(sq) * len(sdb) / tq, 1), "cores": 1, "kind": "port",
+                                   "sample": "2000 queries x 100000 database rows of the same data"}
 
     if rank == 0:
         # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh + tools/pmc_to_traffic.py),
