@@ -75,9 +75,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
 
   for (int cbase = 0; cbase < ndb; cbase += KNN_CHUNK) {
     const int cn = min(KNN_CHUNK, ndb - cbase);
-    uint32_t k1[KNN_KQ], k2[KNN_KQ];
+    uint32_t k1[KNN_KQ], k2[KNN_KQ], s2d[KNN_KQ];  // s2d = distance part of k2
 #pragma unroll
-    for (int k = 0; k < KNN_KQ; k++) { k1[k] = 0xFFFFFFFFu; k2[k] = 0xFFFFFFFFu; }
+    for (int k = 0; k < KNN_KQ; k++) { k1[k] = 0xFFFFFFFFu; k2[k] = 0xFFFFFFFFu; s2d[k] = 0xFFFFFFFFu >> KNN_ROWBITS; }
     for (int t0 = 0; t0 < cn; t0 += KNN_TILE) {
       const int tn = min(KNN_TILE, cn - t0);
       __syncthreads();
@@ -89,6 +89,8 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
         n0 = s_db[2 * j + 2]; n1 = s_db[2 * j + 3];  // next row, in flight while this one is scored
         const uint32_t row = (uint32_t)(t0 + j);
         const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        uint32_t dk[KNN_KQ];
+        bool need = false;
 #pragma unroll
         for (int k = 0; k < KNN_KQ; k++) {
           // 8 xor + 8 popcounts chained through v_bcnt's accumulator operand (the compiler
@@ -100,10 +102,21 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
             const uint32_t x = qr[k][w] ^ bw[w];
             asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
           }
-          const uint32_t key = (d << KNN_ROWBITS) | row;
-          // two smallest keys: k1 <= k2 always, so the new second is the median of the three
-          asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k2[k]) : "v"(k1[k]), "v"(key));
-          k1[k] = min(k1[k], key);
+          dk[k] = d;
+          need = need || d < s2d[k];
+        }
+        // Rows come in ascending order, so a row changes (best, second) only if its distance
+        // is below the second-best distance; after the first few hundred rows that is rare,
+        // and the whole wavefront skips the update.
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+          for (int k = 0; k < KNN_KQ; k++) {
+            const uint32_t key = (dk[k] << KNN_ROWBITS) | row;
+            // two smallest keys: k1 <= k2 always, so the new second is the median of the three
+            asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k2[k]) : "v"(k1[k]), "v"(key));
+            k1[k] = min(k1[k], key);
+            s2d[k] = k2[k] >> KNN_ROWBITS;
+          }
         }
       }
     }
