@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the extractor against the oracle (run on a GPU box):
+random image sizes, feature counts, level counts, scale factors, thresholds and contents.
+    python tools/fuzz_extract.py [n_cases] [seed]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle as O
+from orb_slam2_amd import ORBextractor
+from orb_slam2_amd._lib import OrbHipError
+from orb_slam2_amd.synth import synth_image
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    rows = int(rng.integers(120, 800))
+    cols = int(rows * rng.uniform(0.8, 3.2))
+    nlev = int(rng.integers(1, 9))
+    sf = float(rng.choice([1.2, 1.2, 1.1, 1.3, 1.44]))
+    nf = int(rng.integers(50, 3000))
+    ini, mn = int(rng.integers(8, 40)), int(rng.integers(2, 8))
+    kind = rng.integers(0, 4)
+    img = synth_image(rows, cols, int(rng.integers(0, 1 << 30)), n_shapes=None if kind else 30)
+    if kind == 2:
+        img = (img // 8 * 8).astype(np.uint8)            # plateaus: many equal scores
+    if kind == 3:
+        img = np.clip(img.astype(np.int16) + rng.integers(-25, 26, img.shape), 0, 255).astype(np.uint8)  # noisy: min-threshold cells
+    tag = "%dx%d nf=%d lv=%d sf=%.2f th=%d/%d kind=%d" % (rows, cols, nf, nlev, sf, ini, mn, kind)
+    try:
+        ex = ORBextractor(nf, sf, nlev, ini, mn)
+        kps, desc = ex(img)
+    except OrbHipError as e:
+        print("case %d %s: refused (%s)" % (case, tag, str(e)[:60]))
+        continue
+    rk, rd = O.Extractor(nf, sf, nlev, ini, mn)(img)
+    ok = len(kps) == len(rk)
+    if ok:
+        ok = all(np.array_equal(kps[f], rk[f]) for f in ("x", "y", "octave", "response", "size"))
+        ok = ok and (len(kps) == 0 or (np.abs(kps["angle"] - rk["angle"]).max() <= 1e-4 * 180 / np.pi and (desc == rd).all(1).mean() >= 0.999))
+    if not ok:
+        bad += 1
+        print("MISMATCH case %d %s: %d vs %d keypoints" % (case, tag, len(kps), len(rk)))
+    elif case % 10 == 0:
+        print("case %d %s ok (%d kp, desc identical %.4f) %.0fs" % (case, tag, len(kps), (desc == rd).all(1).mean() if len(kps) else 1.0, time.time() - t0), flush=True)
+print("done: %d cases, %d mismatches" % (n_cases, bad))
+sys.exit(1 if bad else 0)

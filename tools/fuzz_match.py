@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the matchers against the oracle (run on a GPU box): the
+parity tests of tests/test_match_gpu.py with random sizes, thresholds and seeds.
+    python tools/fuzz_match.py [n_rounds] [seed]"""
+import os, sys, time, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pytest
+from oracle import oracle as O
+import test_match_gpu as T
+
+O.lib()
+n_rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+t0 = time.time()
+
+
+def run(name, fn, *args):
+    global bad
+    try:
+        fn(O, *args)
+    except AssertionError:
+        # the tests also assert that the scene is rich enough ("> 100 matches"); only parity counts here
+        tb = traceback.format_exc()
+        if "==" in tb.splitlines()[-2] or "array_equal" in tb or " is " in tb:
+            bad += 1
+            print("MISMATCH %s%r\n%s" % (name, args, tb.splitlines()[-2]), flush=True)
+
+
+for r in range(n_rounds):
+    s = int(rng.integers(0, 1 << 30))
+    ri = lambda a, b: int(rng.integers(a, b))
+    run("frames", T.test_search_by_projection_frames, s, ri(50, 3000), ri(50, 3000), ri(0, 40), bool(ri(0, 2)))
+    run("mappoints", T.test_search_by_projection_mappoints, s, ri(50, 3000), ri(50, 2500), float(rng.choice([1.0, 3.0, 5.0])), float(rng.uniform(0.5, 0.95)))
+    run("triang", T.test_search_for_triangulation, s, ri(100, 2500), ri(100, 2500), bool(ri(0, 2)))
+    run("windowed", T.test_match_windowed_vs_oracle, s, ri(100, 3000), ri(100, 3500), int(rng.choice([50, 100])), bool(ri(0, 2)))
+    run("bow", T.test_search_by_bow_both_overloads, s, ri(100, 2500), ri(100, 2500), float(rng.uniform(0.6, 0.95)), bool(ri(0, 2)), ri(2, 300))
+    run("init", T.test_search_for_initialization, s, ri(200, 3000), ri(10, 300), float(rng.uniform(0.7, 0.99)), bool(ri(0, 2)))
+    run("knn", T.test_knn2_vs_oracle, ri(1, 3000), ri(1, 3000))
+    print("round %d done, %d mismatches, %.0fs" % (r, bad, time.time() - t0), flush=True)
+print("done: %d rounds, %d mismatches" % (n_rounds, bad))
+sys.exit(1 if bad else 0)
