@@ -135,7 +135,8 @@ def test_search_by_projection_mappoints(oracle, seed, nmp, nf, th, ratio):
         mp.mTrackedProjX, mp.mTrackedProjY = float(mps["projx"][i]), float(mps["projy"][i])
         vp.append(mp)
     got_n = ORBmatcher(ratio, True).SearchByProjection(F, vp, th)
-    assert got_n == want_n and want_n > 0
+    assert got_n == want_n
+    assert want_n > 0, "scene too poor"
     for idx in range(nf):
         if want_match[idx] >= 0:
             assert F.mvpMapPoints[idx] is vp[want_match[idx]]
@@ -191,7 +192,8 @@ def test_search_for_triangulation(oracle, seed, n1, n2, ori):
         dict(x=x1, y=y1, octave=o1, angle=a1, desc=d1, has_mp=has1.astype(np.uint8)),
         dict(x=x2, y=y2, octave=o2, angle=a2, desc=d2, has_mp=has2.astype(np.uint8)),
         flat(kf1.mFeatVec), flat(kf2.mFeatVec), F12, (ex, ey), sf, s2, ori)
-    assert got_n == want_n and want_n > 20
+    assert got_n == want_n
+    assert want_n > 20, "scene too poor"
     assert pairs == [(i, int(want_m[i])) for i in range(n1) if want_m[i] >= 0]
 
 
@@ -278,7 +280,8 @@ def test_match_windowed_vs_oracle(oracle, seed, nt, nq, maxd, ori):
           f(q["angle"], "f4"), f(q["desc"], "u1")]
     check(lib().orb_match_windowed(0, FrameBounds(*bounds), nt, *[ptr(a) for a in args], nq, *[ptr(a) for a in qa],
                                    maxd, int(ori), ptr(match), C.byref(nm)))
-    assert want_n > 50 and nm.value == want_n and np.array_equal(match, want_m)
+    assert nm.value == want_n and np.array_equal(match, want_m)
+    assert want_n > 50, "scene too poor"
 
 
 def test_relocalisation_and_sim3_searches(oracle):
@@ -427,7 +430,8 @@ def test_search_by_bow_both_overloads(oracle, seed, n1, n2, ratio, ori, nnodes):
     got = m.SearchByBoW(kf1, fr, out)
     wn, w12 = oracle.search_by_bow(dict(angle=k1["angle"], desc=d1, ok=ok1), dict(angle=k2["angle"], desc=d2, ok=np.ones(n2, np.uint8)),
                                    _flat(kf1.mFeatVec), _flat(fr.mFeatVec), ratio, 50, ori)
-    assert got == wn and wn > 30 and len(out) == n2
+    assert got == wn and len(out) == n2
+    assert wn > 30, "scene too poor"
     want = [None] * n2
     for i1 in range(n1):
         if w12[i1] >= 0:
@@ -442,7 +446,8 @@ def test_search_by_bow_both_overloads(oracle, seed, n1, n2, ratio, ori, nnodes):
     got = m.SearchByBoW(kf1, kf2, out12)
     wn, w12 = oracle.search_by_bow(dict(angle=k1["angle"], desc=d1, ok=ok1), dict(angle=k2["angle"], desc=d2, ok=has2.astype(np.uint8)),
                                    _flat(kf1.mFeatVec), _flat(kf2.mFeatVec), ratio, 49, ori)
-    assert got == wn and wn > 20 and len(out12) == n1
+    assert got == wn and len(out12) == n1
+    assert wn > 20, "scene too poor"
     assert all((a is None and w < 0) or (w >= 0 and a is kf2.mvpMapPoints[w]) for a, w in zip(out12, w12))
 
 
@@ -676,6 +681,7 @@ def test_search_for_initialization(oracle, seed, n, win, ratio, ori):
     got = ORBmatcher(ratio, ori).SearchForInitialization(F1, F2, prev, out, win)
     wn, w12 = oracle.search_for_initialization(b, dict(octave=o1, angle=a1, desc=d1), prev0,
                                                dict(x=x2, y=y2, octave=o2, angle=a2, desc=d2), win, ratio, ori)
-    assert got == wn and wn > 100 and np.array_equal(np.array(out, np.int32), w12)
+    assert got == wn and np.array_equal(np.array(out, np.int32), w12)
+    assert wn > 100, "scene too poor"
     hit = w12 >= 0
     assert np.array_equal(prev[hit, 0], x2[w12[hit]]) and np.array_equal(prev[~hit], prev0[~hit])

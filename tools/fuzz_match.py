@@ -24,7 +24,7 @@ def run(name, fn, *args):
     except AssertionError:
         # the tests also assert that the scene is rich enough ("> 100 matches"); only parity counts here
         tb = traceback.format_exc()
-        if "==" in tb.splitlines()[-2] or "array_equal" in tb or " is " in tb:
+        if "scene too poor" not in tb:
             bad += 1
             print("MISMATCH %s%r\n%s" % (name, args, tb.splitlines()[-2]), flush=True)
 
