@@ -493,7 +493,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
 // Ties of the reference's sort of pair<count, node*> are resolved as if node
 // addresses grew with allocation order (later-created node first).
 // ---------------------------------------------------------------------------
-constexpr int OT_THREADS = 512;
+constexpr int OT_MAXT = 1024;  // workgroup size: 512 for ordinary frames, 1024 when levels hold tens of thousands of candidates
 
 template <int OT_MAXS>  // node slots
 struct OtShared {
@@ -511,7 +511,7 @@ struct OtShared {
   short cumc[OT_MAXS];
   short bykey[OT_MAXS];  // slots of the nodes created by the last pass, by key - first key of that pass
   unsigned char split[OT_MAXS];
-  int wsum[OT_THREADS / 64];
+  int wsum[OT_MAXT / 64];
   int vars[16];
 };
 enum { V_SIZE = 0, V_NSLOTS, V_NEXTSEQ, V_MODE, V_FINISH, V_NE, V_NEWEXP, V_PN, V_GROW, V_NCHILD, V_K };
@@ -521,7 +521,7 @@ constexpr int OT_RPT = 8;  // points per thread that the register-resident form 
 // Visits the points of this thread: f(candidate record, node label&).  With REG the
 // records and labels live in registers (a thread always handles the same points); otherwise
 // they are read from, and labels written back to, global memory.
-template <bool REG, typename F>
+template <bool REG, int OT_THREADS, typename F>
 __device__ __forceinline__ void ot_for_points(int n, int tid, const uint32_t* __restrict__ pts, uint32_t* __restrict__ pn,
                                               uint32_t (&rp)[OT_RPT], uint32_t (&rn)[OT_RPT], F f) {
   if constexpr (REG) {
@@ -529,16 +529,30 @@ __device__ __forceinline__ void ot_for_points(int n, int tid, const uint32_t* __
     for (int k = 0; k < OT_RPT; k++)
       if (tid + k * OT_THREADS < n) f(rp[k], rn[k]);
   } else {
-    for (int p = tid; p < n; p += OT_THREADS) {
-      const uint32_t w0 = pn[p];
-      uint32_t w = w0;
-      f(pts[p], w);
-      if (w != w0) pn[p] = w;
+    // OT_BATCH points per step, loads first, so that their latencies overlap
+    constexpr int OT_BATCH = 16;
+    for (int p0 = tid; p0 < n; p0 += OT_BATCH * OT_THREADS) {
+      uint32_t w0[OT_BATCH], v[OT_BATCH];
+#pragma unroll
+      for (int u = 0; u < OT_BATCH; u++) {
+        const int p = min(p0 + u * OT_THREADS, n - 1);
+        w0[u] = pn[p];
+        v[u] = pts[p];
+      }
+#pragma unroll
+      for (int u = 0; u < OT_BATCH; u++) {
+        const int p = p0 + u * OT_THREADS;
+        if (p < n) {
+          uint32_t w = w0[u];
+          f(v[u], w);
+          if (w != w0[u]) pn[p] = w;
+        }
+      }
     }
   }
 }
 
-template <int OT_MAXS, bool REG>
+template <int OT_MAXS, int OT_THREADS, bool REG>
 __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t* __restrict__ pts,
                                             uint32_t* __restrict__ pn, uint32_t* __restrict__ sel,
                                             int* __restrict__ sel_cnt, const Plan& P, const int n, const int l,
@@ -569,7 +583,7 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
   __syncthreads();
   if constexpr (!REG)
     for (int p = tid; p < n; p += OT_THREADS) pn[p] = 0xFFFFFFFFu;  // so that the first label is always stored
-  ot_for_points<REG>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
+  ot_for_points<REG, OT_THREADS>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
     const int x = v & kCoordMask;
     int r = (int)__fdiv_rn((float)x, hX);
     r = min(max(r, 0), nIni - 1);
@@ -635,7 +649,7 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
       E = S.vars[V_NE];
     }
     // 2. quadrant of every point of such a node (DivideNode's point loop)
-    ot_for_points<REG>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
+    ot_for_points<REG, OT_THREADS>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
       const int s = node & 0xFFFF;
       if (S.count[s] > 1) {
         const int x = v & kCoordMask, y = (v >> kCoordBits) & kCoordMask;
@@ -729,7 +743,7 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
     }
     __syncthreads();
     // 7. move the points of split nodes to their child
-    ot_for_points<REG>(n, tid, pts, pn, rp, rn, [&](uint32_t, uint32_t& node) {
+    ot_for_points<REG, OT_THREADS>(n, tid, pts, pn, rp, rn, [&](uint32_t, uint32_t& node) {
       const int s = node & 0xFFFF;
       if (S.split[s]) node = (uint32_t)(unsigned short)S.cslot[4 * s + (node >> 16)];
     });
@@ -752,7 +766,7 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
   const int nslots = S.vars[V_NSLOTS];
   for (int s = tid; s < nslots; s += OT_THREADS) S.skey[s] = 0;
   __syncthreads();
-  ot_for_points<REG>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
+  ot_for_points<REG, OT_THREADS>(n, tid, pts, pn, rp, rn, [&](uint32_t v, uint32_t& node) {
     const int s = node & 0xFFFF;
     const int x = v & kCoordMask, y = (v >> kCoordBits) & kCoordMask;
     const unsigned long long canon =
@@ -787,7 +801,7 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
   if (tid == 0) sel_cnt[f * P.nlevels + l] = min(S.vars[V_SIZE], L.sel_cap);
 }
 
-template <int OT_MAXS>
+template <int OT_MAXS, int OT_THREADS>
 __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __restrict__ cand_all,
                                                             const int* __restrict__ cand_cnt,
                                                             uint32_t* __restrict__ pnode_all,
@@ -801,8 +815,8 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
   uint32_t* pn = pnode_all + (size_t)f * P.cand_total + L.cand_off;
   uint32_t* sel = sel_all + (size_t)f * P.sel_total + L.sel_off;
   const int n = min(cand_cnt[f * P.nlevels + l], L.cand_cap);
-  if (n <= OT_RPT * OT_THREADS) octree_body<OT_MAXS, true>(S, pts, pn, sel, sel_cnt, P, n, l, f, tid);
-  else octree_body<OT_MAXS, false>(S, pts, pn, sel, sel_cnt, P, n, l, f, tid);
+  if (n <= OT_RPT * OT_THREADS) octree_body<OT_MAXS, OT_THREADS, true>(S, pts, pn, sel, sel_cnt, P, n, l, f, tid);
+  else octree_body<OT_MAXS, OT_THREADS, false>(S, pts, pn, sel, sel_cnt, P, n, l, f, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -1195,28 +1209,32 @@ void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int n
   hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), 2 * (size_t)rows * F_PITCH, st, pyr, P, items,
                      cand, cand_cnt, iniTh, minTh, rows);
 }
-template <int MAXS>
+template <int MAXS, int THREADS>
 static hipError_t launch_octree_t(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel,
                                   int* sel_cnt, const Plan& P, int nframes, hipStream_t st) {
   const size_t lds = sizeof(OtShared<MAXS>);
   if (lds > 64 * 1024) {
-    static bool raised = false;  // per process; the attribute belongs to the function, not the call
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&octree_kernel<MAXS>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      raised = true;
-    }
+    // the attribute belongs to the function (per device): raise it to this size before the launch
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&octree_kernel<MAXS, THREADS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(octree_kernel<MAXS>, dim3(nframes, P.nlevels), dim3(OT_THREADS), lds, st, cand, cand_cnt, pnode,
-                     sel, sel_cnt, P);
+  hipLaunchKernelGGL((octree_kernel<MAXS, THREADS>), dim3(nframes, P.nlevels), dim3(THREADS), lds, st, cand, cand_cnt,
+                     pnode, sel, sel_cnt, P);
   return hipSuccess;
 }
-// slots: enough for the largest level (quota + 3 nodes, dead root slots, slack)
+// slots: enough for the largest level (quota + 3 nodes, dead root slots, slack).  Frames of
+// more than about 1.5 megapixels have tens of thousands of candidates on their first levels:
+// the point loops then dominate and want the larger workgroup.
 hipError_t launch_octree(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel, int* sel_cnt,
                          const Plan& P, int max_slots_needed, int nframes, hipStream_t st) {
-  if (max_slots_needed <= 1024) return launch_octree_t<1024>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
-  return launch_octree_t<2048>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
+  const bool big = (long long)P.lv[0].w * P.lv[0].h > 1500000;
+  if (max_slots_needed <= 1024) {
+    if (big) return launch_octree_t<1024, 1024>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
+    return launch_octree_t<1024, 512>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
+  }
+  if (big) return launch_octree_t<2048, 1024>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
+  return launch_octree_t<2048, 512>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
 }
 void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurItem* items, int nitems, const int* taps,
                  int nframes, hipStream_t st) {
