@@ -81,6 +81,10 @@ struct OrbExtractor {
   // staging for the host-buffer entry points
   uint8_t* d_img = nullptr;
   size_t d_img_bytes = 0;
+  uint8_t* h_img = nullptr;  // pinned staging for host images
+  size_t h_img_bytes = 0;
+  uint8_t* h_out = nullptr;  // pinned staging for keypoints, descriptors and counts
+  size_t h_out_bytes = 0;
   OrbKeyPoint* d_kps = nullptr;
   uint8_t* d_desc = nullptr;
   int* d_nout = nullptr;
@@ -434,6 +438,8 @@ void orb_extractor_destroy(OrbExtractor* h) {
   hipDeviceSynchronize();
   free_plan_buffers(h);
   hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_nout);
+  if (h->h_img) hipHostFree(h->h_img);
+  if (h->h_out) hipHostFree(h->h_out);
   for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
   delete h;
@@ -548,23 +554,51 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
     h->out_cap = need; h->out_frames = n_frames;
   }
   hipStream_t st = h->stream;
-  for (int k = 0; k < n_frames; k++)
-    ORB_HIP_CHECK(hipMemcpy2DAsync(h->d_img + (size_t)k * rows * cols, cols, images + (size_t)k * frame_stride, stride,
-                                   cols, rows, hipMemcpyHostToDevice, st));
+  // Host images go through a pinned staging buffer, packed to rows of `cols` bytes: one
+  // DMA for the batch (a strided copy from pageable memory is far slower than the kernels).
+  if (img_bytes > h->h_img_bytes) {
+    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->h_img) hipHostFree(h->h_img);
+    h->h_img = nullptr; h->h_img_bytes = 0;
+    ORB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_img), img_bytes, hipHostMallocDefault));
+    h->h_img_bytes = img_bytes;
+  }
+  for (int k = 0; k < n_frames; k++) {
+    const uint8_t* src = images + (size_t)k * frame_stride;
+    uint8_t* dst = h->h_img + (size_t)k * rows * cols;
+    if (stride == (size_t)cols) memcpy(dst, src, (size_t)rows * cols);
+    else for (int r = 0; r < rows; r++) memcpy(dst + (size_t)r * cols, src + (size_t)r * stride, cols);
+  }
+  ORB_HIP_CHECK(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, st));
   rc = enqueue(h, n_frames, h->d_img, cols, (size_t)rows * cols, max_kp, h->d_kps, h->d_desc, h->d_nout, st);
   if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipMemcpyAsync(n_out, h->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, st));
+  // results come back through pinned staging as well: two DMAs for the batch, then the valid
+  // part of every frame is copied to the caller's arrays
+  const size_t out_bytes = need * (sizeof(OrbKeyPoint) + 32) + sizeof(int) * (size_t)n_frames;
+  if (out_bytes > h->h_out_bytes) {
+    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->h_out) hipHostFree(h->h_out);
+    h->h_out = nullptr; h->h_out_bytes = 0;
+    ORB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_out), out_bytes, hipHostMallocDefault));
+    h->h_out_bytes = out_bytes;
+  }
+  OrbKeyPoint* s_kps = reinterpret_cast<OrbKeyPoint*>(h->h_out);
+  uint8_t* s_desc = h->h_out + need * sizeof(OrbKeyPoint);
+  int* s_n = reinterpret_cast<int*>(s_desc + need * 32);
+  ORB_HIP_CHECK(hipMemcpyAsync(s_n, h->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, st));
+  ORB_HIP_CHECK(hipMemcpyAsync(s_kps, h->d_kps, sizeof(OrbKeyPoint) * need, hipMemcpyDeviceToHost, st));
+  ORB_HIP_CHECK(hipMemcpyAsync(s_desc, h->d_desc, 32 * need, hipMemcpyDeviceToHost, st));
   ORB_HIP_CHECK(hipStreamSynchronize(st));
   int status = ORBHIP_OK;
   for (int k = 0; k < n_frames; k++) {
+    n_out[k] = s_n[k];
     const int n = std::min(n_out[k], max_kp);
     if (n_out[k] > max_kp) { set_error("max_kp too small: a frame produced " + std::to_string(n_out[k]) + " keypoints"); status = ORBHIP_ERR_CAPACITY; }
     if (n > 0) {
-      ORB_HIP_CHECK(hipMemcpyAsync(keypoints + (size_t)k * max_kp, h->d_kps + (size_t)k * max_kp, sizeof(OrbKeyPoint) * n, hipMemcpyDeviceToHost, st));
-      ORB_HIP_CHECK(hipMemcpyAsync(descriptors + (size_t)k * max_kp * 32, h->d_desc + (size_t)k * max_kp * 32, 32 * (size_t)n, hipMemcpyDeviceToHost, st));
+      memcpy(keypoints + (size_t)k * max_kp, s_kps + (size_t)k * max_kp, sizeof(OrbKeyPoint) * n);
+      memcpy(descriptors + (size_t)k * max_kp * 32, s_desc + (size_t)k * max_kp * 32, 32 * (size_t)n);
     }
   }
-  ORB_HIP_CHECK(hipStreamSynchronize(st));
   return status;
 }
 
