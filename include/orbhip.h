@@ -320,6 +320,37 @@ int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_bes
 int orb_knn2_bruteforce(int device_id, const uint8_t* q, int n_q, const uint8_t* db, int n_db,
                         float ratio, int* best, int* second, int* idx, uint8_t* accept);
 
+/* ---- bag-of-words quantisation (DBoW2 vocabulary tree) ---- */
+
+typedef struct OrbVocabulary OrbVocabulary;
+
+/* Uploads a vocabulary tree as DBoW2::TemplatedVocabulary holds it after loadFromTextFile
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1352-1438): node 0 is the root, node i has
+ * the children children[child_start[i] .. child_start[i] + child_count[i]) in the order the
+ * file lists them (ascending id, every child id above its parent's), node_desc[i] is its
+ * 32-byte FORB descriptor, node_word[i] its word id if it is a leaf (else ignored);
+ * levels = m_L.  Node weights stay with the caller.  The children array has n_nodes - 1
+ * entries. */
+int orb_vocabulary_create(int device_id, int n_nodes, int levels, const int* child_start,
+                          const int* child_count, const int* children, const uint8_t* node_desc,
+                          const int* node_word, OrbVocabulary** out);
+void orb_vocabulary_destroy(OrbVocabulary* v);
+
+/* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup)
+ * (TemplatedVocabulary.h:1232-1273) with FORB::distance (Thirdparty/DBoW2/DBoW2/FORB.cpp)
+ * for n features at once: from the root, step to the child with the smallest Hamming
+ * distance (the first one on ties) until a leaf; word_id[i] = that leaf's word,
+ * node_id[i] = the node passed at depth levels - levelsup (0 if that depth is <= 0 or the
+ * leaf is shallower).  The ordered BowVector / FeatureVector that
+ * transform(features, v, fv, levelsup) (:1141-1208, as Frame::ComputeBoW calls it with
+ * levelsup = 4) builds from these pairs are assembled by the caller.
+ * The _device form takes DEVICE pointers (descriptors 16-byte aligned), is enqueued on
+ * `stream` and not waited for. */
+int orb_bow_transform_device(OrbVocabulary* v, int n, const uint8_t* d_desc, int levelsup,
+                             int* d_word_id, int* d_node_id, void* stream);
+int orb_bow_transform(OrbVocabulary* v, int n, const uint8_t* desc, int levelsup, int* word_id,
+                      int* node_id);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -360,3 +360,32 @@ def knn2_bruteforce(q, db, ratio):
     acc = np.empty(max(nq, 1), np.uint8)
     lib().orc_knn2_bruteforce(_p(q), nq, _p(db), len(db), C.c_float(ratio), _p(best), _p(second), _p(idx), _p(acc))
     return best[:nq].copy(), second[:nq].copy(), idx[:nq].copy(), acc[:nq].copy()
+
+
+def bow_transform(parent, is_leaf, node_desc, node_weight, levels, feats, levelsup):
+    """Vocabulary in file-record form (parent id, leaf flag, descriptor, weight per node; node 0
+    = root).  Returns (word_id, node_id, weight) per feature."""
+    parent, leaf, nd = _i32(parent), _u8(is_leaf), _u8(node_desc)
+    wt = np.ascontiguousarray(node_weight, np.float64)
+    feats = _u8(feats)
+    n = len(feats)
+    word, node = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32)
+    w = np.empty(max(n, 1), np.float64)
+    L = lib()
+    L.orc_bow_transform.restype = C.c_int
+    L.orc_bow_transform(C.c_int(len(parent)), _p(parent), _p(leaf), _p(nd), _p(wt), C.c_int(levels), C.c_int(n),
+                        _p(feats), C.c_int(levelsup), _p(word), _p(node), _p(w))
+    return word[:n].copy(), node[:n].copy(), w[:n].copy()
+
+
+def bow_vector_l1(word_id, weight):
+    """Returns (ids, values, keep): the L1-normalised BowVector in ascending word order and
+    the per-feature 'not stopped' flags."""
+    word_id = _i32(word_id)
+    weight = np.ascontiguousarray(weight, np.float64)
+    n = len(word_id)
+    ids, vals, keep = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.float64), np.empty(max(n, 1), np.uint8)
+    L = lib()
+    L.orc_bow_vector_l1.restype = C.c_int
+    m = L.orc_bow_vector_l1(C.c_int(n), _p(word_id), _p(weight), _p(ids), _p(vals), _p(keep))
+    return ids[:m].copy(), vals[:m].copy(), keep[:n].astype(bool)

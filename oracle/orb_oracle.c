@@ -1308,3 +1308,75 @@ ORC_API void orc_knn2_bruteforce(const uint8_t* q, int nq, const uint8_t* db, in
     accept[i] = (uint8_t)(bi >= 0 && (float)b < ratio * (float)s);
   }
 }
+
+/* ---- DBoW2 vocabulary tree: transform ----
+ * The tree arrives the way loadFromTextFile reads it (Thirdparty/DBoW2/DBoW2/
+ * TemplatedVocabulary.h:1352-1438): one record per node 1..n_nodes-1 in file order with its
+ * parent id and leaf flag; a node's children are its records in file order (push_back,
+ * :1406) and word ids number the leaves in file order (:1422-1429).
+ * Per feature (:1232-1273): from the root take the child with the smallest FORB::distance
+ * (Thirdparty/DBoW2/DBoW2/FORB.cpp:81-112, the same bit count as DescriptorDistance), the
+ * first child on ties ('d < best_d'), until a leaf; nid = node passed at depth L - levelsup.
+ * A leaf shallower than that depth leaves *nid unset in the reference; 0 is written here.
+ * out_weight may be null. */
+ORC_API int orc_bow_transform(int n_nodes, const int* parent, const uint8_t* is_leaf, const uint8_t* node_desc,
+                              const double* node_weight, int levels, int n, const uint8_t* feat, int levelsup,
+                              int* word_id, int* node_id, double* out_weight) {
+  int* cnt = (int*)calloc((size_t)n_nodes + 1, sizeof(int));
+  int* start = (int*)calloc((size_t)n_nodes + 1, sizeof(int));
+  int* kids = (int*)malloc(sizeof(int) * (size_t)n_nodes);
+  int* word = (int*)malloc(sizeof(int) * (size_t)n_nodes);
+  int nwords = 0;
+  for (int i = 1; i < n_nodes; i++) cnt[parent[i]]++;
+  for (int i = 0; i < n_nodes; i++) start[i + 1] = start[i] + cnt[i];
+  memset(cnt, 0, sizeof(int) * (size_t)n_nodes);
+  for (int i = 1; i < n_nodes; i++) kids[start[parent[i]] + cnt[parent[i]]++] = i;
+  word[0] = -1;
+  for (int i = 1; i < n_nodes; i++) word[i] = is_leaf[i] ? nwords++ : -1;
+  const int nid_level = levels - levelsup;
+  for (int f = 0; f < n; f++) {
+    const uint8_t* q = feat + 32 * (size_t)f;
+    int final_id = 0, level = 0, nid = 0;
+    do {
+      ++level;
+      const int* c = kids + start[final_id];
+      const int nc = cnt[final_id];
+      final_id = c[0];
+      double best_d = (double)orc_descriptor_distance(q, node_desc + 32 * (size_t)final_id);
+      for (int k = 1; k < nc; k++) {
+        double d = (double)orc_descriptor_distance(q, node_desc + 32 * (size_t)c[k]);
+        if (d < best_d) { best_d = d; final_id = c[k]; }
+      }
+      if (level == nid_level) nid = final_id;
+    } while (cnt[final_id] > 0);
+    word_id[f] = word[final_id];
+    node_id[f] = nid;
+    if (out_weight) out_weight[f] = node_weight[final_id];
+  }
+  free(cnt); free(start); free(kids); free(word);
+  return nwords;
+}
+
+/* BowVector of transform(features, v, fv, levelsup) for TF / TF_IDF weighting with L1
+ * scoring (TemplatedVocabulary.h:1159-1176, 1207; BowVector.cpp:34-46, 62-84): weights
+ * with w > 0 are added per word in feature order, the norm is the sum of |value| in
+ * ascending word order, every value is divided by it.  keep[f] = (w > 0).
+ * out_id / out_val need room for n entries; returns the number of distinct words. */
+ORC_API int orc_bow_vector_l1(int n, const int* word_id, const double* w, int* out_id, double* out_val,
+                              uint8_t* keep) {
+  int m = 0;
+  for (int f = 0; f < n; f++) {
+    keep[f] = (uint8_t)(w[f] > 0);
+    if (!keep[f]) continue;
+    int lo = 0, hi = m; /* lower_bound */
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (out_id[mid] < word_id[f]) lo = mid + 1; else hi = mid; }
+    if (lo < m && out_id[lo] == word_id[f]) { out_val[lo] += w[f]; continue; }
+    memmove(out_id + lo + 1, out_id + lo, sizeof(int) * (size_t)(m - lo));
+    memmove(out_val + lo + 1, out_val + lo, sizeof(double) * (size_t)(m - lo));
+    out_id[lo] = word_id[f]; out_val[lo] = w[f]; m++;
+  }
+  double norm = 0.0;
+  for (int k = 0; k < m; k++) norm += fabs(out_val[k]);
+  if (norm > 0.0) for (int k = 0; k < m; k++) out_val[k] /= norm;
+  return m;
+}
