@@ -101,6 +101,38 @@ class ORBVocabulary:
                                            " ".join(str(int(b)) for b in self.node_desc[i]),
                                            repr(float(self.node_weight[i]))))
 
+    _BIN_NODE = np.dtype([("parent", "<i4"), ("desc", "u1", (32,)), ("weight", "<f4"), ("leaf", "u1")])
+
+    def loadFromBinaryFile(self, filename):
+        """TemplatedVocabulary.h:1444-1489: header nb_nodes (root included), size_node, k, L,
+        scoring, weighting as 32-bit values, then one 41-byte record per node 1..nb_nodes-1:
+        parent id, 32 descriptor bytes, float weight, leaf flag."""
+        self._release()
+        try:
+            with open(filename, "rb") as f:
+                head = np.fromfile(f, "<i4", 6)
+                if len(head) < 6 or head[1] != self._BIN_NODE.itemsize:
+                    return False
+                rec = np.fromfile(f, self._BIN_NODE, max(int(head[0]) - 1, 0))
+        except OSError:
+            return False
+        n = len(rec) + 1
+        parent, leaf = np.zeros(n, np.int32), np.zeros(n, np.uint8)
+        desc, weight = np.zeros((n, 32), np.uint8), np.zeros(n, np.float64)
+        parent[1:], leaf[1:], desc[1:], weight[1:] = rec["parent"], rec["leaf"] != 0, rec["desc"], rec["weight"]
+        self.set_nodes(head[2], head[3], parent, leaf, desc, weight, head[4], head[5])
+        return True
+
+    def saveToBinaryFile(self, filename):
+        """TemplatedVocabulary.h:1495-1515 (weights narrow to float, as there)."""
+        n = len(self.parent)
+        rec = np.zeros(n - 1, self._BIN_NODE)
+        rec["parent"], rec["desc"] = self.parent[1:], self.node_desc[1:]
+        rec["weight"], rec["leaf"] = self.node_weight[1:].astype(np.float32), self.is_leaf[1:]
+        with open(filename, "wb") as f:
+            np.array([n, self._BIN_NODE.itemsize, self.m_k, self.m_L, self.m_scoring, self.m_weighting], "<i4").tofile(f)
+            rec.tofile(f)
+
     @classmethod
     def synthetic(cls, k=10, L=4, seed=0, device_id=0, p_tie=0.1, p_early_leaf=0.05, p_stop=0.02):
         """Random k-ary tree of depth L in the id order hierarchical k-means creates nodes

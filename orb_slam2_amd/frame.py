@@ -99,9 +99,15 @@ class Frame:
         self.mvpMapPoints = [None] * self.N
         # DBoW2::FeatureVector: vocabulary node id -> feature indices, ordered by node id
         self.mFeatVec = dict(sorted((feat_vec or {}).items()))
+        self.mBowVec = {}
         self.mnScaleLevels = len(self.mvScaleFactors)
         self.mfScaleFactor = float(self.mvScaleFactors[1]) if self.mnScaleLevels > 1 else 1.2
         self.mfLogScaleFactor = np.float32(np.log(np.float32(self.mfScaleFactor)))
+
+    def ComputeBoW(self, vocabulary):
+        """reference src/Frame.cc:483-497 / src/KeyFrame.cc:120-131: once per frame, levelsup 4"""
+        if not self.mBowVec:
+            self.mBowVec, self.mFeatVec = vocabulary.transform(self.mDescriptors, 4)
 
 
 class KeyFrame(Frame):

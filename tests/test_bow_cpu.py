@@ -77,6 +77,21 @@ def test_text_round_trip(tmp_path):
     assert not ORBVocabulary().loadFromTextFile(str(bad))
 
 
+def test_binary_round_trip(tmp_path):
+    voc = ORBVocabulary.synthetic(k=5, L=3, seed=10)
+    path = str(tmp_path / "voc.bin")
+    voc.saveToBinaryFile(path)
+    raw = open(path, "rb").read()
+    assert len(raw) == 24 + 41 * (len(voc.parent) - 1)
+    back = ORBVocabulary()
+    assert back.loadFromBinaryFile(path)
+    assert (back.m_k, back.m_L) == (5, 3)
+    for name in ("parent", "is_leaf", "node_desc", "word_id"):
+        assert np.array_equal(getattr(back, name), getattr(voc, name)), name
+    assert np.array_equal(back.node_weight, voc.node_weight.astype(np.float32).astype(np.float64))
+    assert not ORBVocabulary().loadFromBinaryFile(str(tmp_path / "missing.bin"))
+
+
 def test_children_csr_keeps_file_order():
     voc = ORBVocabulary.synthetic(k=4, L=3, seed=5)
     start, count, children = voc.children_csr()
