@@ -96,6 +96,17 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
                              int cols, size_t stride, size_t frame_stride, int max_kp,
                              OrbKeyPoint* d_keypoints, uint8_t* d_descriptors, int* d_n_out,
                              void* stream);
+
+/* Pixel format of the images handed to the orb_extract* calls that follow: 1 = 8-bit grey
+ * (default, what ORBextractor::operator() asserts, src/ORBextractor.cc:1229), 3 or 4 =
+ * interleaved colour, converted to grey while level 0 of the pyramid is written - the
+ * cvtColor(CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) that
+ * Tracking::GrabImageMonocular / GrabImageStereo / GrabImageRGBD run first
+ * (src/Tracking.cc:203-216); rgb_order = the reference's mbRGB (Camera.RGB).  `stride` and
+ * `frame_stride` stay in bytes (stride >= cols * channels).  OpenCV's 8-bit conversion is
+ * (R*9798 + G*19235 + B*3735 + 2^14) >> 15; alpha is ignored. */
+int orb_extractor_set_input_format(OrbExtractor* h, int channels, int rgb_order);
+
 /* Waits for the handle's own stream, which the host-buffer entry points and the
  * accessors below use. */
 int orb_extractor_sync(OrbExtractor* h);

@@ -389,3 +389,12 @@ def bow_vector_l1(word_id, weight):
     L.orc_bow_vector_l1.restype = C.c_int
     m = L.orc_bow_vector_l1(C.c_int(n), _p(word_id), _p(weight), _p(ids), _p(vals), _p(keep))
     return ids[:m].copy(), vals[:m].copy(), keep[:n].astype(bool)
+
+
+def cvt_gray(img, rgb_order=True):
+    """img: (rows, cols, 3|4) uint8 -> (rows, cols) grey, as cv::cvtColor computes it."""
+    img = _u8(img)
+    rows, cols, ch = img.shape
+    out = np.empty((rows, cols), np.uint8)
+    lib().orc_cvt_gray(_p(img), C.c_int(rows), C.c_int(cols), C.c_int(cols * ch), C.c_int(ch), C.c_int(int(rgb_order)), _p(out))
+    return out

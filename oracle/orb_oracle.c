@@ -1380,3 +1380,19 @@ ORC_API int orc_bow_vector_l1(int n, const int* word_id, const double* w, int* o
   if (norm > 0.0) for (int k = 0; k < m; k++) out_val[k] /= norm;
   return m;
 }
+
+/* cv::cvtColor 8-bit colour -> grey as the reference calls it before building a Frame
+ * (src/Tracking.cc:203-216: CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY).
+ * OpenCV 4.x integer path (imgproc color_rgb, RGB2Gray<uchar>): 15-bit BT.601 weights
+ * R 9798, G 19235, B 3735, rounded: (sum + 2^14) >> 15.  (OpenCV 2.x / 3.x used 14-bit
+ * weights 4899, 9617, 1868: a few pixels differ by one.)  Alpha is ignored. */
+ORC_API void orc_cvt_gray(const uint8_t* src, int rows, int cols, int stride, int channels, int rgb_order,
+                          uint8_t* dst /* rows x cols, packed */) {
+  const int kr = 9798, kg = 19235, kb = 3735;
+  for (int y = 0; y < rows; y++)
+    for (int x = 0; x < cols; x++) {
+      const uint8_t* p = src + (size_t)y * stride + (size_t)x * channels;
+      const int r = rgb_order ? p[0] : p[2], g = p[1], b = rgb_order ? p[2] : p[0];
+      dst[(size_t)y * cols + x] = (uint8_t)((r * kr + g * kg + b * kb + (1 << 14)) >> 15);
+    }
+}

@@ -13,6 +13,7 @@ namespace orbhip {
 
 // launchers and limits defined next to the kernels
 void launch_pyr_level0(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, int, hipStream_t);
+void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, uint8_t*, const Plan&, int, hipStream_t);
 void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
 void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, uint32_t*, int*, int, int, int, hipStream_t);
 hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, int, hipStream_t);
@@ -92,6 +93,8 @@ struct OrbExtractor {
   int out_frames = 0;
   // stage timing
   bool profiling = false;
+  int channels = 1;       // interleaved bytes per input pixel: 1 grey, 3, 4
+  bool rgb_order = true;  // first colour byte is red (the reference's Camera.RGB setting)
   std::vector<hipEvent_t> ev;  // ORBHIP_NUM_STAGES + 1 events per profiled call
   int prof_calls = 0;          // profiled calls since the times were last read
 };
@@ -329,7 +332,8 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   }
   ORB_HIP_CHECK(hipMemsetAsync(h->d_cand_cnt, 0, sizeof(int) * (size_t)P.nlevels * nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[0], st));
-  launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, nframes, st);
+  if (h->channels == 1) launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, nframes, st);
+  else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->d_pyr, P, nframes, st);
   for (int l = 1; l < P.nlevels; l++) {
     const OrbExtractor::TileInfo& ti = h->tile[l];
     if (ti.ok)
@@ -482,14 +486,22 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
     ORB_HIP_CHECK(hipMemsetAsync(d_n_out, 0, sizeof(int) * n_frames, (hipStream_t)stream));
     return ORBHIP_OK;
   }
-  if (!d_images || !d_keypoints || !d_descriptors || max_kp <= 0 || stride < (size_t)cols) {
-    set_error("null buffer, max_kp <= 0 or stride < cols"); return ORBHIP_ERR_ARG;
+  if (!d_images || !d_keypoints || !d_descriptors || max_kp <= 0 || stride < (size_t)cols * h->channels) {
+    set_error("null buffer, max_kp <= 0 or stride < cols * channels"); return ORBHIP_ERR_ARG;
   }
   DeviceGuard g(h->device);
   int rc = ensure_plan(h, rows, cols, n_frames);
   if (rc != ORBHIP_OK) return rc;
   return enqueue(h, n_frames, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out,
                  (hipStream_t)stream);
+}
+
+int orb_extractor_set_input_format(OrbExtractor* h, int channels, int rgb_order) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  if (channels != 1 && channels != 3 && channels != 4) { set_error("channels must be 1, 3 or 4"); return ORBHIP_ERR_ARG; }
+  h->channels = channels;
+  h->rgb_order = rgb_order != 0;
+  return ORBHIP_OK;
 }
 
 int orb_extractor_sync(OrbExtractor* h) {
@@ -530,13 +542,14 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   if (!h || !n_out) { set_error("null argument"); return ORBHIP_ERR_ARG; }
   if (n_frames <= 0) return ORBHIP_OK;
   if (rows <= 0 || cols <= 0) { for (int k = 0; k < n_frames; k++) n_out[k] = 0; return ORBHIP_OK; }
-  if (!images || !keypoints || !descriptors || max_kp <= 0 || stride < (size_t)cols) {
-    set_error("null buffer, max_kp <= 0 or stride < cols"); return ORBHIP_ERR_ARG;
+  const size_t row_bytes = (size_t)cols * h->channels;
+  if (!images || !keypoints || !descriptors || max_kp <= 0 || stride < row_bytes) {
+    set_error("null buffer, max_kp <= 0 or stride < cols * channels"); return ORBHIP_ERR_ARG;
   }
   DeviceGuard g(h->device);
   int rc = ensure_plan(h, rows, cols, n_frames);
   if (rc != ORBHIP_OK) return rc;
-  const size_t img_bytes = (size_t)rows * cols * n_frames;
+  const size_t img_bytes = (size_t)rows * row_bytes * n_frames;
   if (img_bytes > h->d_img_bytes) {
     ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
     hipFree(h->d_img); h->d_img = nullptr; h->d_img_bytes = 0;
@@ -554,7 +567,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
     h->out_cap = need; h->out_frames = n_frames;
   }
   hipStream_t st = h->stream;
-  // Host images go through a pinned staging buffer, packed to rows of `cols` bytes: one
+  // Host images go through a pinned staging buffer, packed to rows of `row_bytes` bytes: one
   // DMA for the batch (a strided copy from pageable memory is far slower than the kernels).
   if (img_bytes > h->h_img_bytes) {
     ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -565,12 +578,12 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   }
   for (int k = 0; k < n_frames; k++) {
     const uint8_t* src = images + (size_t)k * frame_stride;
-    uint8_t* dst = h->h_img + (size_t)k * rows * cols;
-    if (stride == (size_t)cols) memcpy(dst, src, (size_t)rows * cols);
-    else for (int r = 0; r < rows; r++) memcpy(dst + (size_t)r * cols, src + (size_t)r * stride, cols);
+    uint8_t* dst = h->h_img + (size_t)k * rows * row_bytes;
+    if (stride == row_bytes) memcpy(dst, src, (size_t)rows * row_bytes);
+    else for (int r = 0; r < rows; r++) memcpy(dst + (size_t)r * row_bytes, src + (size_t)r * stride, row_bytes);
   }
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, st));
-  rc = enqueue(h, n_frames, h->d_img, cols, (size_t)rows * cols, max_kp, h->d_kps, h->d_desc, h->d_nout, st);
+  rc = enqueue(h, n_frames, h->d_img, row_bytes, (size_t)rows * row_bytes, max_kp, h->d_kps, h->d_desc, h->d_nout, st);
   if (rc != ORBHIP_OK) return rc;
   // results come back through pinned staging as well: two DMAs for the batch, then the valid
   // part of every frame is copied to the caller's arrays

@@ -60,6 +60,58 @@ __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restri
   *reinterpret_cast<uint4*>(pyr + (size_t)f * slab + L.off + (size_t)row * L.pitch + c16) = out;
 }
 
+// Level 0 from an interleaved colour image: cv::cvtColor(..., CV_RGB2GRAY / CV_BGR2GRAY /
+// CV_RGBA2GRAY / CV_BGRA2GRAY) of the reference's Tracking::GrabImage* (src/Tracking.cc:203-216)
+// folded into the copy above, so the grey image never exists in memory.  8-bit cvtColor is
+// integer: (c0*k0 + c1*k1 + c2*k2 + 2^14) >> 15 with the 15-bit BT.601 weights
+// R 9798, G 19235, B 3735 (they sum to 2^15, so the result fits a byte); alpha is ignored.
+// A thread writes 16 slab bytes from 16*CH source bytes of any alignment.
+template <int CH>
+__global__ __launch_bounds__(256) void pyr_level0_color_kernel(const uint8_t* __restrict__ img, size_t stride,
+                                                               size_t frame_stride, uint8_t* __restrict__ pyr,
+                                                               unsigned long long slab, LevelGeom L, int k0, int k1,
+                                                               int k2) {
+  const int nchunk = L.pitch >> 4;
+  const int t = blockIdx.y * 256 + threadIdx.x;
+  const int row = t / nchunk;  // padded row
+  if (row >= L.h + 2 * kEdge) return;
+  const int c16 = (t - row * nchunk) * 16;
+  const int f = blockIdx.x;
+  const int iy = refl101(row - kEdge, L.h);
+  const uint8_t* S = img + (size_t)f * frame_stride + (size_t)iy * stride;
+  const int px0 = c16 - kXOff;
+  uint32_t o[4] = {0, 0, 0, 0};
+  if (px0 >= 4 && px0 + 20 <= L.w) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(S + (size_t)px0 * CH);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    uint32_t x[4 * CH + 1], w[4 * CH];
+#pragma unroll
+    for (int j = 0; j <= 4 * CH; j++) x[j] = q[j];
+#pragma unroll
+    for (int j = 0; j < 4 * CH; j++) w[j] = __builtin_amdgcn_alignbyte(x[j + 1], x[j], sh);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int b = k * CH;
+      const int c0 = (w[b >> 2] >> (8 * (b & 3))) & 255;
+      const int c1 = (w[(b + 1) >> 2] >> (8 * ((b + 1) & 3))) & 255;
+      const int c2 = (w[(b + 2) >> 2] >> (8 * ((b + 2) & 3))) & 255;
+      o[k >> 2] |= (uint32_t)((c0 * k0 + c1 * k1 + c2 * k2 + (1 << 14)) >> 15) << (8 * (k & 3));
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int px = px0 + k;
+      if (px >= -kEdge && px < L.w + kEdge) {
+        const uint8_t* c = S + (size_t)refl101(px, L.w) * CH;
+        o[k >> 2] |= (uint32_t)((c[0] * k0 + c[1] * k1 + c[2] * k2 + (1 << 14)) >> 15) << (8 * (k & 3));
+      }
+    }
+  }
+  *reinterpret_cast<uint4*>(pyr + (size_t)f * slab + L.off + (size_t)row * L.pitch + c16) =
+      make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // Level l >= 1: cv::resize(INTER_LINEAR, 8U fixed point) of level l-1's un-padded
 // pixels, then the reflected frame of level l itself
 // (reference src/ORBextractor.cc:1367-1389).  Frame pixels are recomputed from the
@@ -1182,6 +1234,20 @@ void launch_pyr_level0(const uint8_t* img, size_t stride, size_t frame_stride, u
   const int pieces = (L.pitch / 16) * (L.h + 2 * kEdge);
   dim3 grid(nframes, (pieces + 255) / 256);
   hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L);
+}
+void launch_pyr_level0_color(const uint8_t* img, size_t stride, size_t frame_stride, int channels, bool rgb_order,
+                             uint8_t* pyr, const Plan& P, int nframes, hipStream_t st) {
+  const LevelGeom& L = P.lv[0];
+  const int pieces = (L.pitch / 16) * (L.h + 2 * kEdge);
+  dim3 grid(nframes, (pieces + 255) / 256);
+  const int kr = 9798, kg = 19235, kb = 3735;
+  const int k0 = rgb_order ? kr : kb, k2 = rgb_order ? kb : kr;
+  if (channels == 3)
+    hipLaunchKernelGGL(pyr_level0_color_kernel<3>, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, k0,
+                       kg, k2);
+  else
+    hipLaunchKernelGGL(pyr_level0_color_kernel<4>, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, k0,
+                       kg, k2);
 }
 void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, const YTab* yt, int nframes,
                        hipStream_t st) {

@@ -27,6 +27,8 @@ class ORBextractor:
                                                        ptr(self._sigma2), ptr(self._inv_sigma2)))
         self._scale_factor = float(np.float32(scaleFactor))
         self._frames = 0
+        self._channels = 1
+        self.mbRGB = True  # colour order of 3/4-channel input (reference Tracking::mbRGB, Camera.RGB)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -77,18 +79,27 @@ class ORBextractor:
         kps, desc = self.extract_batch(image[None])
         return kps[0], desc[0]
 
+    def set_input_format(self, channels, rgb_order=True):
+        """1 = grey; 3 / 4 = interleaved colour, converted while level 0 is written (the
+        cvtColor of reference src/Tracking.cc:203-216)."""
+        check(self._lib.orb_extractor_set_input_format(self._h, int(channels), int(bool(rgb_order))))
+        self._channels = int(channels)
+
     def extract_batch(self, images):
-        """images: (n, rows, cols) uint8.  Returns lists of per-frame keypoints/descriptors."""
+        """images: (n, rows, cols) uint8 grey, or (n, rows, cols, 3|4) colour in the order
+        self.mbRGB says.  Returns lists of per-frame keypoints/descriptors."""
         images = np.asarray(images)
-        assert images.dtype == np.uint8 and images.ndim == 3, "CV_8UC1 images expected"
-        n, rows, cols = images.shape
+        assert images.dtype == np.uint8 and images.ndim in (3, 4), "8-bit images expected"
+        ch = images.shape[3] if images.ndim == 4 else 1
+        self.set_input_format(ch, self.mbRGB)
+        n, rows, cols = images.shape[:3]
         if not images.flags.c_contiguous:
             images = np.ascontiguousarray(images)
         cap = self.max_keypoints(rows, cols)
         kps = np.zeros((n, cap), KP_DTYPE)
         desc = np.zeros((n, cap, 32), np.uint8)
         nout = np.zeros(n, np.int32)
-        check(self._lib.orb_extract_batch(self._h, n, ptr(images), rows, cols, cols, rows * cols, cap,
+        check(self._lib.orb_extract_batch(self._h, n, ptr(images), rows, cols, cols * ch, rows * cols * ch, cap,
                                           ptr(kps), ptr(desc), ptr(nout)))
         self._frames = n
         return [kps[k, :nout[k]].copy() for k in range(n)], [desc[k, :nout[k]].copy() for k in range(n)]
@@ -96,7 +107,7 @@ class ORBextractor:
     def extract_batch_device(self, d_images, n, rows, cols, d_kps, d_desc, d_nout, max_kp, stream=None,
                              stride=None, frame_stride=None):
         """Device-pointer form (ints holding device addresses); enqueues and returns."""
-        stride = cols if stride is None else stride
+        stride = cols * self._channels if stride is None else stride
         frame_stride = rows * stride if frame_stride is None else frame_stride
         check(self._lib.orb_extract_batch_device(self._h, int(n), C.c_void_p(d_images), int(rows), int(cols),
                                                  stride, frame_stride, int(max_kp), C.c_void_p(d_kps),

@@ -217,3 +217,75 @@ def test_full_size_properties_batch():
     q, _ = ex.features_per_level()
     counts = np.bincount(k1["octave"], minlength=8)
     assert ((counts >= q) & (counts <= q + 3)).all()
+
+
+def _colour_image(rows, cols, ch, seed):
+    """A colour image whose grey value has corners: the synthetic grey scene modulated per
+    channel, plus noise, so that the three weights all matter."""
+    from orb_slam2_amd.synth import synth_image
+    rng = np.random.default_rng(seed)
+    base = synth_image(rows, cols, seed).astype(np.int32)
+    img = np.stack([np.clip(base + rng.integers(-40, 41, base.shape), 0, 255) for _ in range(3)], 2)
+    if ch == 4:
+        img = np.concatenate([img, rng.integers(0, 256, (rows, cols, 1))], 2)
+    return np.ascontiguousarray(img.astype(np.uint8))
+
+
+@pytest.mark.parametrize("rows,cols,ch,rgb", [(376, 1241, 3, True), (376, 1241, 3, False), (480, 640, 4, True),
+                                              (480, 752, 4, False), (211, 333, 3, True)])
+def test_colour_input_is_converted_in_level0(oracle, rows, cols, ch, rgb):
+    """Colour frames through the extractor equal cvtColor + grey extraction, stage by stage."""
+    from orb_slam2_amd import ORBextractor
+    nlevels = 8 if min(rows, cols) >= 240 else 2
+    img = _colour_image(rows, cols, ch, 5)
+    gray = oracle.cvt_gray(img, rgb)
+    assert len(np.unique(gray)) > 100
+    ex = ORBextractor(1000, 1.2, nlevels, 20, 7)
+    ex.mbRGB = rgb
+    kps, desc = ex(img)
+    assert np.array_equal(ex.pyramid_level(0), gray)
+    ref = oracle.Extractor(1000, 1.2, nlevels, 20, 7)
+    rk, rd = ref(gray)
+    assert len(rk) > 50, "scene too poor"
+    check_against(kps, desc, rk, rd)
+    check_stages(ex, ref, nlevels)
+    # the handle goes back to grey input without being rebuilt
+    k2, d2 = ex(gray)
+    assert np.array_equal(k2, kps) and np.array_equal(d2, desc)
+
+
+def test_colour_device_path_strided_batch(oracle):
+    """Device-resident colour frames with row padding and an odd (4-byte misaligned) start."""
+    torch = pytest.importorskip("torch")
+    from orb_slam2_amd import ORBextractor
+    rows, cols, n = 240, 321, 3
+    stride, fstride = cols * 3 + 5, rows * (cols * 3 + 5) + 7
+    buf = np.zeros(1 + n * fstride, np.uint8)
+    frames = [_colour_image(rows, cols, 3, 20 + k) for k in range(n)]
+    for k in range(n):
+        v = buf[1 + k * fstride:1 + k * fstride + rows * stride].reshape(rows, stride)
+        v[:, :cols * 3] = frames[k].reshape(rows, cols * 3)
+    ex = ORBextractor(800, 1.2, 8, 20, 7)
+    ex.set_input_format(3, False)
+    cap = ex.max_keypoints(rows, cols)
+    d = torch.from_numpy(buf).cuda()
+    kps = torch.zeros((n, cap, 6), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d.data_ptr() + 1, n, rows, cols, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(), cap,
+                            stream=torch.cuda.current_stream().cuda_stream, stride=stride, frame_stride=fstride)
+    torch.cuda.synchronize()
+    ref = oracle.Extractor(800, 1.2, 8, 20, 7)
+    for k in range(n):
+        gray = oracle.cvt_gray(frames[k], False)
+        assert np.array_equal(ex.pyramid_level(0, k), gray)
+        rk, rd = ref(gray)
+        m = int(nout[k])
+        assert m == len(rk) and m > 50
+        assert np.array_equal(kps[k, :m, 0].cpu().numpy(), rk["x"]) and np.array_equal(kps[k, :m, 1].cpu().numpy(), rk["y"])
+        assert (desc[k, :m].cpu().numpy() == rd).all(1).mean() >= DESC_MIN_IDENTICAL
+    # a stride that cannot hold a colour row is refused
+    from orb_slam2_amd._lib import OrbHipError
+    with pytest.raises(OrbHipError):
+        ex.extract_batch_device(d.data_ptr(), n, rows, cols, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(), cap,
+                                stride=cols, frame_stride=fstride)

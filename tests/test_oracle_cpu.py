@@ -349,3 +349,14 @@ def test_stereo_band_search_against_definition(oracle):
         assert bi[i] == (bj if best < 75 else -1)
         cnt += best < 75
     assert n == cnt and cnt >= 20
+
+
+def test_cvt_gray_known_answers(oracle):
+    """cv::cvtColor 8-bit colour -> grey: pure colours, white, and the channel orders."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [10, 200, 30]]], np.uint8)
+    # round((9798, 19235, 3735) * 255 / 32768) = 76, 150, 29; weights sum to 2^15 so white stays 255
+    assert oracle.cvt_gray(px, True)[0].tolist() == [76, 150, 29, 255, 0, (10 * 9798 + 200 * 19235 + 30 * 3735 + 16384) >> 15]
+    assert oracle.cvt_gray(px, False)[0].tolist()[:3] == [29, 150, 76]
+    rgba = np.concatenate([px, np.full((1, 6, 1), 77, np.uint8)], 2)
+    assert np.array_equal(oracle.cvt_gray(rgba, True), oracle.cvt_gray(px, True))
+    assert np.array_equal(oracle.cvt_gray(rgba[..., [2, 1, 0, 3]], False), oracle.cvt_gray(px, True))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extraction rate at the other configured shapes (device-resident batch, one GPU):
-    python tools/bench_shapes.py"""
+    python tools/bench_shapes.py [channels]      (1 grey, 3 RGB, 4 RGBA: converted while level 0 is written)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,13 +9,17 @@ from orb_slam2_amd import _lib
 from orb_slam2_amd.extractor import ORBextractor
 from orb_slam2_amd.synth import synth_sequence
 
+CH = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda", 0)
 for name, rows, cols, nf, B in [("TUM 640x480/1000", 480, 640, 1000, 128), ("KITTI 1241x376/2000", 376, 1241, 2000, 128),
                                  ("EuRoC 752x480/1200", 480, 752, 1200, 128), ("4K 3840x2160/4000", 2160, 3840, 4000, 16)]:
     seq = synth_sequence(rows, cols, min(B, 8), seed=5, step=2)
     seq = np.concatenate([seq] * (B // len(seq)), 0)
+    if CH > 1:  # grey replicated into the colour channels: same corners, 3-4x the input bytes
+        seq = np.ascontiguousarray(np.repeat(seq[..., None], CH, 3))
     d_img = torch.from_numpy(seq).to(dev)
     ex = ORBextractor(nf, 1.2, 8, 20, 7, device=0)
+    ex.set_input_format(CH, True)
     max_kp = ex.max_keypoints(rows, cols)
     d_kps = torch.zeros((B, max_kp, 6), dtype=torch.float32, device=dev)
     d_desc = torch.zeros((B, max_kp, 32), dtype=torch.uint8, device=dev)
