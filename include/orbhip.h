@@ -331,6 +331,16 @@ int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_bes
 int orb_knn2_bruteforce(int device_id, const uint8_t* q, int n_q, const uint8_t* db, int n_db,
                         float ratio, int* best, int* second, int* idx, uint8_t* accept);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:386-469) for n_points map points
+ * at once.  desc holds the descriptors that observe each point (the rows the reference
+ * collects at :407-416, in that order), point p's in rows start[p] .. start[p+1]) (start has
+ * n_points + 1 entries, start[0] = 0).  best_idx[p] = position within the point's rows of the
+ * descriptor with the least median distance to all of them (median = sorted row element
+ * (int)(0.5 * (N - 1)), the first such descriptor on ties), -1 for a point without rows;
+ * best_median[p] (may be null) = that median. */
+int orb_distinctive_descriptors(int device_id, int n_points, const int* start, const uint8_t* desc,
+                                int* best_idx, int* best_median);
+
 /* ---- bag-of-words quantisation (DBoW2 vocabulary tree) ---- */
 
 typedef struct OrbVocabulary OrbVocabulary;

@@ -398,3 +398,13 @@ def cvt_gray(img, rgb_order=True):
     out = np.empty((rows, cols), np.uint8)
     lib().orc_cvt_gray(_p(img), C.c_int(rows), C.c_int(cols), C.c_int(cols * ch), C.c_int(ch), C.c_int(int(rgb_order)), _p(out))
     return out
+
+
+def distinctive_descriptor(desc):
+    """-> (index of the least-median descriptor, that median)."""
+    desc = _u8(desc).reshape(-1, 32)
+    med = C.c_int()
+    L = lib()
+    L.orc_distinctive_descriptor.restype = C.c_int
+    idx = L.orc_distinctive_descriptor(C.c_int(len(desc)), _p(desc), C.byref(med))
+    return idx, med.value

@@ -1396,3 +1396,23 @@ ORC_API void orc_cvt_gray(const uint8_t* src, int rows, int cols, int stride, in
       dst[(size_t)y * cols + x] = (uint8_t)((r * kr + g * kg + b * kb + (1 << 14)) >> 15);
     }
 }
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:421-463): pairwise distances,
+ * each row sorted, median = row[0.5 * (N - 1)], least median wins, first on ties.
+ * Returns the index, *median_out the median (may be null); -1 for n = 0. */
+static int cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+ORC_API int orc_distinctive_descriptor(int n, const uint8_t* desc, int* median_out) {
+  if (n <= 0) { if (median_out) *median_out = -1; return -1; }
+  int* row = (int*)malloc(sizeof(int) * (size_t)n);
+  int best_median = 0x7FFFFFFF, best_idx = 0;
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++)
+      row[j] = i == j ? 0 : orc_descriptor_distance(desc + 32 * (size_t)i, desc + 32 * (size_t)j);
+    qsort(row, (size_t)n, sizeof(int), cmp_int);
+    const int median = row[(int)(0.5 * (n - 1))];
+    if (median < best_median) { best_median = median; best_idx = i; }
+  }
+  free(row);
+  if (median_out) *median_out = best_median;
+  return best_idx;
+}

@@ -36,7 +36,7 @@ EXPORTS = [
     "orb_get_pyramid_level", "orb_get_blurred_level", "orb_get_fast_candidates", "orb_get_level_keypoints",
     "orb_hamming_distance_pairs", "orb_search_by_projection_frames", "orb_search_by_projection_mappoints",
     "orb_search_for_triangulation", "orb_knn2_device", "orb_knn2_merge_device", "orb_knn2_bruteforce",
-    "orb_vocabulary_create", "orb_vocabulary_destroy", "orb_bow_transform_device", "orb_bow_transform",
+    "orb_vocabulary_create", "orb_vocabulary_destroy", "orb_bow_transform_device", "orb_bow_transform", "orb_distinctive_descriptors",
 ]
 
 
@@ -98,6 +98,7 @@ def lib():
     L.orb_vocabulary_destroy.restype = None
     L.orb_bow_transform_device.argtypes = [vp, i, vp, i, vp, vp, vp]
     L.orb_bow_transform.argtypes = [vp, i, vp, i, vp, vp]
+    L.orb_distinctive_descriptors.argtypes = [i, i, vp, vp, vp, vp]
     _lib = L
     return L
 

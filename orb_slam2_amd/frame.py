@@ -58,6 +58,10 @@ class MapPoint:
     def isBad(self):
         return self._bad
 
+    def ComputeDistinctiveDescriptors(self):
+        """reference src/MapPoint.cc:386-469; see compute_distinctive_descriptors for many points"""
+        compute_distinctive_descriptors([self])
+
     # scale-invariance range and viewing direction (reference src/MapPoint.cc:527-568);
     # set by UpdateNormalAndDepth in the reference, plain attributes here
     mfMinDistance = 0.0
@@ -78,6 +82,34 @@ class MapPoint:
         ratio = np.float32(np.float32(self.mfMaxDistance) / np.float32(currentDist))
         nScale = int(np.ceil(np.float32(np.log(ratio)) / np.float32(frame.mfLogScaleFactor)))
         return min(max(nScale, 0), frame.mnScaleLevels - 1)
+
+
+def compute_distinctive_descriptors(map_points, device_id=0):
+    """MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:386-469) for a list of
+    map points in one GPU call: each point that is not bad takes, of the descriptors of the
+    keyframes (not bad) that observe it, the one with the least median distance to the others.
+    Observations are visited in insertion order (the reference's std::map orders them by
+    keyframe address, which decides nothing but ties between equal medians)."""
+    from . import _lib
+    rows, start, todo = [], [0], []
+    for mp in map_points:
+        if mp.isBad():
+            continue
+        obs = [pKF.mDescriptors[idx] for pKF, idx in mp.mObservations.items() if not pKF.isBad()]
+        if not obs:
+            continue
+        rows.extend(obs)
+        start.append(len(rows))
+        todo.append(mp)
+    if not todo:
+        return
+    desc = np.ascontiguousarray(np.stack(rows), np.uint8)
+    start = np.asarray(start, np.int32)
+    best = np.empty(len(todo), np.int32)
+    _lib.check(_lib.lib().orb_distinctive_descriptors(int(device_id), len(todo), _lib.ptr(start), _lib.ptr(desc),
+                                                      _lib.ptr(best), None))
+    for mp, s0, b in zip(todo, start[:-1], best):
+        mp._desc = desc[s0 + b].copy()
 
 
 class Frame:
@@ -112,6 +144,11 @@ class Frame:
 
 class KeyFrame(Frame):
     """Adds the accessors the keyframe searches use (map point list, pose, image bounds)."""
+
+    mbBad = False
+
+    def isBad(self):
+        return self.mbBad
 
     def GetMapPoint(self, idx):
         return self.mvpMapPoints[idx]

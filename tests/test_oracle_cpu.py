@@ -360,3 +360,16 @@ def test_cvt_gray_known_answers(oracle):
     rgba = np.concatenate([px, np.full((1, 6, 1), 77, np.uint8)], 2)
     assert np.array_equal(oracle.cvt_gray(rgba, True), oracle.cvt_gray(px, True))
     assert np.array_equal(oracle.cvt_gray(rgba[..., [2, 1, 0, 3]], False), oracle.cvt_gray(px, True))
+
+
+def test_distinctive_descriptor_known_answers(oracle):
+    """Least-median descriptor (reference src/MapPoint.cc:421-463) on hand-checked rows."""
+    d = np.zeros((4, 32), np.uint8)
+    d[1, 0] = 0b1      # distance 1 from rows 0, 2
+    d[3, :4] = 255     # 32 bits away from 0/2, 31 or 33 from 1
+    # rows sorted: r0 [0,0,1,32] r1 [0,1,1,31] r2 [0,0,1,32] r3 [0,31,32,32]; element (int)(0.5*3) = 1
+    assert oracle.distinctive_descriptor(d) == (0, 0)
+    d2 = d[[3, 1, 0, 2]]
+    assert oracle.distinctive_descriptor(d2) == (2, 0)
+    assert oracle.distinctive_descriptor(d[:1]) == (0, 0)
+    assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == (-1, -1)
