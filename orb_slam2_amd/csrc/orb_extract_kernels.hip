@@ -244,7 +244,7 @@ constexpr int F_USEW = 240;   // widest run of cell interiors per workgroup
 constexpr int F_PITCH = 272;  // LDS row pitch; a wavefront's 64 lanes x 4 columns cover a staged row
 constexpr int F_MAXH = 66;    // tallest cell view (hCell <= 59, + 6)
 constexpr int F_MAXCELLS = 16;
-constexpr int F_QCAP = 64 + 256;  // a wave's queue: carried-over remainder + one row of survivors
+constexpr int F_QCAP = 64 + 256;  // a wave's queue: carried-over remainder + one row of survivors (re-queued entries while there is room)
 constexpr int F_CCAP = 512;       // corners kept per wavefront before falling back to a dense sweep
 static_assert(3 + F_USEW + 6 <= 256, "a staged row must fit 64 lanes x 4 columns");
 
@@ -254,34 +254,42 @@ __device__ __forceinline__ uint32_t as_u32(fast_s2 v) { return __builtin_bit_cas
 __device__ __forceinline__ fast_s2 pk_min(fast_s2 a, fast_s2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ fast_s2 pk_max(fast_s2 a, fast_s2 b) { return __builtin_elementwise_max(a, b); }
 
-// V = max(A, B) of the pixel at p (see above).  min over an arc of (c - p) is c - max over
-// the arc of p, so A = c - min_k max(p[k..k+8]) and B = max_k min(p[k..k+8]) - c: sliding
-// maxima and minima of the raw ring bytes.  On packed 16-bit lanes every register holds
-// (p[k], 255 - p[k]), so one max network yields both.
-__device__ __forceinline__ int fast_v(const uint8_t* p /* centre in LDS */) {
+// One polarity of V for the pixel at p (see above): A = c - min_k max(p[k..k+8]) for a ring
+// darker than the centre, B = max_k min(p[k..k+8]) - c = (255 - c) - min_k max(255 - p[k..k+8])
+// for a brighter one, so B is A on the complemented bytes.  A pixel is a corner by at most
+// one of the two (two arcs of 9 do not fit in 16), and the four compass points say which can be.
+// Opposite ring pixels share a register, (p[k], p[k+8]) on packed 16-bit lanes, so eight
+// registers hold the ring and each step of the sliding maximum is eight operations; where a
+// window wraps past p[15] the neighbour register is used with its halves exchanged.
+__device__ __forceinline__ fast_s2 swap2(fast_s2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ int fast_v1(const uint8_t* p /* centre in LDS */, int t, bool dark_only, bool& again) {
   const int c = p[0];
-  const fast_s2 flip = {0, 255};
-  fast_s2 P[16];
   const int offs[16] = {3 * F_PITCH,      3 * F_PITCH + 1,  2 * F_PITCH + 2,  F_PITCH + 3,
                         3,                -F_PITCH + 3,     -2 * F_PITCH + 2, -3 * F_PITCH + 1,
                         -3 * F_PITCH,     -3 * F_PITCH - 1, -2 * F_PITCH - 2, -F_PITCH - 3,
                         -3,               F_PITCH - 3,      2 * F_PITCH - 2,  3 * F_PITCH - 1};
+  uint32_t r[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const short v = (short)p[offs[k]];
-    const fast_s2 q = {v, v};
-    P[k] = q ^ flip;
-  }
-  fast_s2 m2[16], m4[16];
+  for (int k = 0; k < 16; k++) r[k] = p[offs[k]];
+  // which polarity can hold: an arc of 9 contains two adjacent compass points
+  const bool br = (int)min(max(r[0], r[8]), max(r[4], r[12])) > c + t;
+  const bool dk = (int)max(min(r[0], r[8]), min(r[4], r[12])) < c - t;
+  const bool bright = br && !dark_only;
+  again = bright && dk;  // both can: the caller runs this pixel once more for the darker ring
+  const uint32_t flip = bright ? 0x00FF00FFu : 0u;
+  fast_s2 Q[8], m2[8], m4[8], m8[8];
 #pragma unroll
-  for (int k = 0; k < 16; k++) m2[k] = pk_max(P[k], P[(k + 1) & 15]);
+  for (int k = 0; k < 8; k++) Q[k] = as_s2((r[k] | (r[k + 8] << 16)) ^ flip);
 #pragma unroll
-  for (int k = 0; k < 16; k++) m4[k] = pk_max(m2[k], m2[(k + 2) & 15]);
+  for (int k = 0; k < 8; k++) m2[k] = pk_max(Q[k], k < 7 ? Q[k + 1] : swap2(Q[0]));
+#pragma unroll
+  for (int k = 0; k < 8; k++) m4[k] = pk_max(m2[k], k < 6 ? m2[k + 2] : swap2(m2[k - 6]));
+#pragma unroll
+  for (int k = 0; k < 8; k++) m8[k] = pk_max(m4[k], k < 4 ? m4[k + 4] : swap2(m4[k - 4]));
   fast_s2 best = {32767, 32767};
 #pragma unroll
-  for (int k = 0; k < 16; k++) best = pk_min(best, pk_max(pk_max(m4[k], m4[(k + 4) & 15]), P[(k + 8) & 15]));
-  // best = (min_k max_arc p, 255 - max_k min_arc p)
-  return max(c - (int)best.x, 255 - (int)best.y - c);
+  for (int k = 0; k < 8; k++) best = pk_min(best, pk_max(m8[k], swap2(Q[k])));  // arcs k and k + 8
+  return (bright ? 255 - c : c) - min((int)best.x, (int)best.y);
 }
 
 // NMS decision for the pixel whose V byte is at q: strictly greater than the 8
@@ -355,36 +363,40 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   __syncthreads();
 
   const unsigned long long lt_mask = (1ull << lane) - 1;
-  // the lane's four LDS columns and the cells they belong to
-  int colcell[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int x = 4 * lane + j - xoff;
-    colcell[j] = (x >= 0 && x < wi) ? x / wCell : -1;
-  }
-
   unsigned cellmask = (1u << item.ncells) - 1;  // cells to (re)compute in this pass
   int ncorner = 0;                              // wave-uniform: entries in this wave's corner list
   bool overflow = false;                        // wave-uniform: corner list too small, sweep densely
   for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? iniTh : minTh;
-    bool mine[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) mine[j] = colcell[j] >= 0 && ((cellmask >> colcell[j]) & 1u);
     int qn = 0;  // wave-uniform: entries waiting in this wave's queue
 
     // full test of queue entries [0, n) (n <= 64 per call chunk), corners appended
     auto drain = [&](int head, int n) {
       const int k = head + lane;
-      bool corner = false;
+      bool corner = false, again = false;
       int e = 0;
       if (lane < n) {
         e = s_list[wave][k];
-        const int off = ((e >> 8) + 3) * F_PITCH + (e & 0xFF);
-        const int v = fast_v(&s_img[off]);
+        const int off = (((e >> 8) & 0x7F) + 3) * F_PITCH + (e & 0xFF);
+        const int v = fast_v1(&s_img[off], t, (e & 0x8000) != 0, again);
         corner = v > t;
-        s_v[off] = (uint8_t)(corner ? v : 0);
+        if (corner) s_v[off] = (uint8_t)v;  // the V map starts at 0 (staging, or the clearing before pass 2)
       }
+      // a pixel that either polarity could make a corner (rare) goes to the queue's tail once
+      // more, marked (bit 15) for the darker ring
+      const unsigned long long ma = __ballot(again);
+      if (ma) {
+        if (qn + __popcll(ma) <= F_QCAP) {
+          if (again) s_list[wave][qn + __popcll(ma & lt_mask)] = (uint16_t)(e | 0x8000);
+          qn += __popcll(ma);
+        } else if (again) {  // no room left in the queue: the second polarity right here
+          bool unused;
+          const int off = (((e >> 8) & 0x7F) + 3) * F_PITCH + (e & 0xFF);
+          const int v = fast_v1(&s_img[off], t, true, unused);
+          if (v > t) { corner = true; s_v[off] = (uint8_t)v; }
+        }
+      }
+      e &= 0x7FFF;
       const unsigned long long m = __ballot(corner);
       const int nc = __popcll(m);
       if (ncorner + nc > F_CCAP) overflow = true;
@@ -392,60 +404,91 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       if (!overflow) ncorner += nc;
     };
 
-    // ---- V map for the masked cells.  A wavefront takes every fourth row; a lane tests
-    // four adjacent pixels on packed 16-bit lanes.  Survivors of the quick reject go to the
-    // wave's queue, which is drained 64 entries at a time (full test on all lanes); the
-    // remainder is carried to the next row.  No workgroup barrier inside: the queues are
+    // ---- V map for the masked cells, one run of adjacent masked cells at a time (the first
+    // pass has a single run: the whole strip).  A lane tests four adjacent pixels; a run that
+    // needs no more than 16 or 32 lanes per row puts 4 or 2 rows side by side in the wavefront,
+    // so the second pass costs what its cells cost, not what the strip costs.  Survivors of the
+    // quick reject go to the wave's queue, which is drained 64 entries at a time (full test on
+    // all lanes); the remainder is carried on.  No workgroup barrier inside: the queues are
     // private to the wave and LDS operations of one wave complete in order.
-    for (int y = wave; y < hi; y += F_THREADS / 64) {
-      const uint8_t* rowp = &s_img[(y + 3) * F_PITCH + 4 * lane];
-      const uint32_t C = *reinterpret_cast<const uint32_t*>(rowp);
-      const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4);
-      const uint32_t R = *reinterpret_cast<const uint32_t*>(rowp + 4);
-      const uint32_t U = *reinterpret_cast<const uint32_t*>(rowp - 3 * F_PITCH);
-      const uint32_t D = *reinterpret_cast<const uint32_t*>(rowp + 3 * F_PITCH);
-      const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1);  // pixels x-3
-      const uint32_t E = __builtin_amdgcn_alignbyte(R, C, 3);   // pixels x+3
-      // per pixel: brighter / darker than the centre by more than t at the four compass
-      // points.  Nine contiguous ring pixels always contain two adjacent compass points:
-      // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12).  The comparisons are done per
-      // byte lane (byte-select operands), their results are wave masks combined on the scalar unit.
+    for (unsigned runs = cellmask; runs;) {  // uniform
+      const int c0 = __builtin_ctz(runs);
+      const int len = __builtin_ctz(~(runs >> c0));
+      runs &= ~(((1u << len) - 1u) << c0);
+      const int x0 = c0 * wCell, x1 = min((c0 + len) * wCell, wi);  // interior columns of the run
+      const int lc0 = (x0 + xoff) & ~3;                             // its first LDS dword
+      const int nl = ((x1 + xoff) - lc0 + 3) >> 2;                  // lanes a row needs (<= 64)
+      const int lsh = nl <= 16 ? 4 : nl <= 32 ? 5 : 6;
+      const int rps = 64 >> lsh;  // rows per wavefront step
+      const int li = lane & ((1 << lsh) - 1), sub = lane >> lsh;
+      const int col4 = lc0 + 4 * li;
+      bool mine[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int c = (int)((C >> (8 * j)) & 0xFFu);
-        const int hi = c + t, lo = c - t;
-        const int p0 = (int)((D >> (8 * j)) & 0xFFu), p8 = (int)((U >> (8 * j)) & 0xFFu);
-        const int p4 = (int)((E >> (8 * j)) & 0xFFu), p12 = (int)((W >> (8 * j)) & 0xFFu);
-        const bool br = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));
-        const bool dk = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo));
-        const bool ok = mine[j] & (br | dk);
-        const unsigned long long m = __ballot(ok);
-        if (ok) s_list[wave][qn + __popcll(m & lt_mask)] = (uint16_t)((y << 8) | (4 * lane + j));
-        qn += __popcll(m);
+        const int x = col4 + j - xoff;
+        mine[j] = li < nl && x >= x0 && x < x1;
       }
-      if (qn >= 64) {
-        int head = 0;
-        for (; head + 64 <= qn; head += 64) drain(head, 64);
-        const int rem = qn - head;
-        const int e = lane < rem ? (int)s_list[wave][head + lane] : 0;
-        if (lane < rem) s_list[wave][lane] = (uint16_t)e;
-        qn = rem;
+      for (int yb = wave * rps; yb < hi; yb += (F_THREADS / 64) * rps) {
+        const int y = min(yb + sub, hi - 1);
+        const bool vy = yb + sub < hi;
+        const uint8_t* rowp = &s_img[(y + 3) * F_PITCH + col4];
+        const uint32_t C = *reinterpret_cast<const uint32_t*>(rowp);
+        const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4);
+        const uint32_t R = *reinterpret_cast<const uint32_t*>(rowp + 4);
+        const uint32_t U = *reinterpret_cast<const uint32_t*>(rowp - 3 * F_PITCH);
+        const uint32_t D = *reinterpret_cast<const uint32_t*>(rowp + 3 * F_PITCH);
+        const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1);  // pixels x-3
+        const uint32_t E = __builtin_amdgcn_alignbyte(R, C, 3);   // pixels x+3
+        // per pixel: brighter / darker than the centre by more than t at the four compass
+        // points.  Nine contiguous ring pixels always contain two adjacent compass points:
+        // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12).  The comparisons are done per
+        // byte lane (byte-select operands), their results are wave masks combined on the scalar unit.
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int c = (int)((C >> (8 * j)) & 0xFFu);
+          const int hi = c + t, lo = c - t;
+          const int p0 = (int)((D >> (8 * j)) & 0xFFu), p8 = (int)((U >> (8 * j)) & 0xFFu);
+          const int p4 = (int)((E >> (8 * j)) & 0xFFu), p12 = (int)((W >> (8 * j)) & 0xFFu);
+          const bool br = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));
+          const bool dk = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo));
+          const bool ok = vy & mine[j] & (br | dk);
+          const unsigned long long m = __ballot(ok);
+          if (ok) s_list[wave][qn + __popcll(m & lt_mask)] = (uint16_t)((y << 8) | (col4 + j));
+          qn += __popcll(m);
+        }
+        if (qn >= 64) {
+          int head = 0;
+          for (; head + 64 <= qn; head += 64) drain(head, 64);
+          const int rem = qn - head;
+          const int e = lane < rem ? (int)s_list[wave][head + lane] : 0;
+          if (lane < rem) s_list[wave][lane] = (uint16_t)e;
+          qn = rem;
+        }
       }
     }
-    if (qn) drain(0, qn);
+    for (int head = 0; head < qn;) {  // qn may grow by re-queued entries
+      const int n = min(64, qn - head);
+      drain(head, n);
+      head += n;
+    }
     if (lane == 0) s_ncorner[wave] = overflow ? -1 : ncorner;
     __syncthreads();
     // ---- cell-local NMS, count per cell: over the corner lists (or densely on overflow)
-    const bool any_overflow = s_ncorner[0] < 0 || s_ncorner[1] < 0 || s_ncorner[2] < 0 || s_ncorner[3] < 0;
+    bool any_overflow = false;
+#pragma unroll
+    for (int w = 0; w < F_THREADS / 64; w++) any_overflow |= s_ncorner[w] < 0;
     if (!any_overflow) {
       for (int k = lane; k < ncorner; k += 64) {
         const int e = s_corner[wave][k];
-        const int ex = (e & 0xFF) - xoff, ey = e >> 8;
+        const int ex = (e & 0xFF) - xoff, ey = (e >> 8) & 0x7F;
         const int ecj = ex / wCell, exc = ex - ecj * wCell;
         if (!((cellmask >> ecj) & 1u)) continue;
         const uint8_t* q = &s_v[(ey + 3) * F_PITCH + (e & 0xFF)];
         const int v = q[0];
-        if (v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1)) atomicAdd(&s_cnt[ecj], 1);
+        if (v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1)) {
+          atomicAdd(&s_cnt[ecj], 1);
+          s_corner[wave][k] = (uint16_t)(e | 0x8000);  // bit 15: survives the suppression, goes out
+        }
       }
     } else {
       const int x = tid;  // dense sweep: a thread per interior column
@@ -489,7 +532,40 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     __syncthreads();
   }
 
-  // ---- reserve output range, emit
+  // ---- emit.  Each wavefront reserves room for the corners it has marked with one atomic of
+  // its own and writes them; no workgroup-wide step.  (The order within a level's list is
+  // arbitrary; the quad-tree kernel does not depend on it.)
+  uint32_t* out = cand_all + (size_t)f * P.cand_total + L.cand_off;
+  bool any_overflow = false;
+#pragma unroll
+  for (int w = 0; w < F_THREADS / 64; w++) any_overflow |= s_ncorner[w] < 0;
+  if (!any_overflow) {
+    int nk = 0;
+    for (int k0 = 0; k0 < ncorner; k0 += 64) {
+      const int k = k0 + lane;
+      nk += __popcll(__ballot(k < ncorner && (s_corner[wave][k] & 0x8000)));
+    }
+    if (nk == 0) return;  // wave-uniform
+    int wbase = 0;
+    if (lane == 0) wbase = atomicAdd(&cand_cnt[f * P.nlevels + item.level], nk);
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+    for (int k0 = 0; k0 < ncorner; k0 += 64) {
+      const int k = k0 + lane;
+      const int e = k < ncorner ? (int)s_corner[wave][k] : 0;
+      const bool kept = (e & 0x8000) != 0;
+      const unsigned long long m = __ballot(kept);
+      if (kept) {
+        const int ex = (e & 0xFF) - xoff, ey = (e >> 8) & 0x7F;
+        const int v = s_v[(ey + 3) * F_PITCH + (e & 0xFF)];
+        const int slot = wbase + __popcll(m & lt_mask);
+        const int xr = xb + 3 + ex - kBorder, yr = iniY + 3 + ey - kBorder;
+        if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
+      }
+      wbase += __popcll(m);
+    }
+    return;
+  }
+  // corner lists overflowed: one reservation for the workgroup, dense sweep of the V map
   if (tid == 0) {
     int tot = 0;
     for (int c = 0; c < item.ncells; c++) tot += s_cnt[c];
@@ -499,23 +575,8 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   }
   __syncthreads();
   if (s_total == 0) return;
-  uint32_t* out = cand_all + (size_t)f * P.cand_total + L.cand_off;
   const int gbase = s_base;
-  const bool any_overflow = s_ncorner[0] < 0 || s_ncorner[1] < 0 || s_ncorner[2] < 0 || s_ncorner[3] < 0;
-  if (!any_overflow) {
-    for (int k = lane; k < ncorner; k += 64) {
-      const int e = s_corner[wave][k];
-      const int ex = (e & 0xFF) - xoff, ey = e >> 8;
-      const int ecj = ex / wCell, exc = ex - ecj * wCell;
-      const uint8_t* q = &s_v[(ey + 3) * F_PITCH + (e & 0xFF)];
-      const int v = q[0];
-      if (v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1)) {
-        const int slot = gbase + atomicAdd(&s_emit, 1);
-        const int xr = xb + 3 + ex - kBorder, yr = iniY + 3 + ey - kBorder;
-        if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
-      }
-    }
-  } else if (tid < wi) {
+  if (tid < wi) {
     const int x = tid, cj = x / wCell, xc = x - cj * wCell;
     for (int y = 0; y < hi; y++) {
       const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + xoff];
