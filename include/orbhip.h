@@ -154,6 +154,26 @@ typedef struct OrbFrameBounds {
   float min_x, max_x, min_y, max_y;
 } OrbFrameBounds;
 
+/* Pinhole camera with the 4- or 5-coefficient distortion model of the settings file
+ * (Frame::mK, Frame::mDistCoef: k1, k2, p1, p2 and optionally k3). */
+typedef struct OrbCamera {
+  float fx, fy, cx, cy;
+  float k1, k2, p1, p2, k3;
+} OrbCamera;
+
+/* Frame::UndistortKeyPoints (src/Frame.cc:502-553) for a batch of frames in the layout the
+ * extractor writes: d_kps_un[f][i] = d_kps[f][i] with pt replaced by
+ * cv::undistortPoints(pt, K, distCoef, R = I, P = K) (five iterations in double, result rounded
+ * to float), for i < min(d_n[f], max_kp); a plain copy if k1 == 0, as in the reference.  Device
+ * pointers (d_kps_un may equal d_kps); enqueued on `stream`, not waited for. */
+int orb_undistort_keypoints_device(int device_id, int n_frames, int max_kp, const OrbKeyPoint* d_kps,
+                                   const int* d_n, OrbCamera cam, OrbKeyPoint* d_kps_un, void* stream);
+/* The same map for n host points (x, y interleaved). */
+int orb_undistort_points(int device_id, int n, const float* xy, OrbCamera cam, float* xy_un);
+/* Frame::ComputeImageBounds (src/Frame.cc:560-596): mnMinX, mnMaxX, mnMinY, mnMaxY from the
+ * undistorted image corners (the image size itself if k1 == 0).  Host arithmetic only. */
+int orb_compute_image_bounds(int rows, int cols, OrbCamera cam, OrbFrameBounds* out);
+
 /* ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono)
  * (src/ORBmatcher.cc:1633-1788), for n_pairs independent (Last, Cur) frame pairs
  * with the same intrinsics; pair p uses slices [p*max_last, ...) / [p*max_cur, ...)

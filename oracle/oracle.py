@@ -408,3 +408,23 @@ def distinctive_descriptor(desc):
     L.orc_distinctive_descriptor.restype = C.c_int
     idx = L.orc_distinctive_descriptor(C.c_int(len(desc)), _p(desc), C.byref(med))
     return idx, med.value
+
+
+def undistort_points(xy, K, dist):
+    """xy: (n, 2) float32; K = (fx, fy, cx, cy); dist = (k1, k2, p1, p2[, k3])."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    K4 = np.asarray(K, np.float32)
+    d = np.zeros(5, np.float32)
+    d[:len(dist)] = dist
+    out = np.empty_like(xy)
+    lib().orc_undistort_points(C.c_int(len(xy)), _p(xy), _p(K4), _p(d), _p(out))
+    return out
+
+
+def image_bounds(rows, cols, K, dist):
+    """Frame::ComputeImageBounds (reference src/Frame.cc:560-596) -> (minX, maxX, minY, maxY)."""
+    if len(dist) == 0 or np.float32(dist[0]) == 0:
+        return (0.0, float(cols), 0.0, float(rows))
+    c = undistort_points([[0, 0], [cols, 0], [0, rows], [cols, rows]], K, dist)
+    return (float(min(c[0, 0], c[2, 0])), float(max(c[1, 0], c[3, 0])),
+            float(min(c[0, 1], c[1, 1])), float(max(c[2, 1], c[3, 1])))

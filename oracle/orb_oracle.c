@@ -1416,3 +1416,47 @@ ORC_API int orc_distinctive_descriptor(int n, const uint8_t* desc, int* median_o
   if (median_out) *median_out = best_median;
   return best_idx;
 }
+
+/* cv::undistortPoints(src, dst, K, distCoeffs, R = Mat(), P = K) as Frame::UndistortKeyPoints
+ * and Frame::ComputeImageBounds call it (src/Frame.cc:529-534, 579), restated from OpenCV 4.x
+ * cvUndistortPointsInternal with every term it evaluates: 32-bit inputs widened to double,
+ * default criteria (MAX_ITER, 5) = exactly five iterations, distortion vector k[0..13] with
+ * k1 k2 p1 p2 k3 and zeros, identity tilt, RR = P * I, result narrowed to float.
+ * dist has 5 entries (k3 = 0 for the 4-coefficient model). */
+ORC_API void orc_undistort_points(int n, const float* xy, const float* K4 /* fx fy cx cy */, const float* dist,
+                                  float* out) {
+  const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  double k[14] = {0};
+  for (int i = 0; i < 5; i++) k[i] = dist[i];
+  const double RR[3][3] = {{fx * 1 + 0 * 0 + cx * 0, fx * 0 + 0 * 1 + cx * 0, fx * 0 + 0 * 0 + cx * 1},
+                           {0 * 1 + fy * 0 + cy * 0, 0 * 0 + fy * 1 + cy * 0, 0 * 0 + fy * 0 + cy * 1},
+                           {0, 0, 1}};
+  for (int i = 0; i < n; i++) {
+    double x = xy[2 * i], y = xy[2 * i + 1];
+    const double u = x, v = y;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    { /* tilt compensation with tau = 0: the inverse tilt matrix is the identity */
+      const double vx = 1 * x + 0 * y + 0 * 1, vy = 0 * x + 1 * y + 0 * 1, vz = 0 * x + 0 * y + 1 * 1;
+      const double invProj = vz ? 1. / vz : 1;
+      x = invProj * vx;
+      y = invProj * vy;
+    }
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+    const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+    const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+    out[2 * i] = (float)(xx * ww);
+    out[2 * i + 1] = (float)(yy * ww);
+  }
+}

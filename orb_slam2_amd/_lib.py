@@ -20,6 +20,10 @@ class OrbHipError(RuntimeError):
         self.code = code
 
 
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
 class FrameBounds(C.Structure):
     _fields_ = [("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
 
@@ -37,6 +41,7 @@ EXPORTS = [
     "orb_hamming_distance_pairs", "orb_search_by_projection_frames", "orb_search_by_projection_mappoints",
     "orb_search_for_triangulation", "orb_knn2_device", "orb_knn2_merge_device", "orb_knn2_bruteforce",
     "orb_vocabulary_create", "orb_vocabulary_destroy", "orb_bow_transform_device", "orb_bow_transform", "orb_distinctive_descriptors",
+    "orb_undistort_keypoints_device", "orb_undistort_points", "orb_compute_image_bounds",
 ]
 
 
@@ -99,6 +104,9 @@ def lib():
     L.orb_bow_transform_device.argtypes = [vp, i, vp, i, vp, vp, vp]
     L.orb_bow_transform.argtypes = [vp, i, vp, i, vp, vp]
     L.orb_distinctive_descriptors.argtypes = [i, i, vp, vp, vp, vp]
+    L.orb_undistort_keypoints_device.argtypes = [i, i, i, vp, vp, Camera, vp, vp]
+    L.orb_undistort_points.argtypes = [i, i, vp, Camera, vp]
+    L.orb_compute_image_bounds.argtypes = [i, i, Camera, C.POINTER(FrameBounds)]
     _lib = L
     return L
 

@@ -136,6 +136,28 @@ class Frame:
         self.mfScaleFactor = float(self.mvScaleFactors[1]) if self.mnScaleLevels > 1 else 1.2
         self.mfLogScaleFactor = np.float32(np.log(np.float32(self.mfScaleFactor)))
 
+    @classmethod
+    def from_raw(cls, keypoints, descriptors, scale_factors, level_sigma2, K, dist_coef, rows, cols, device_id=0,
+                 **kw):
+        """The part of the reference's Frame constructor between ExtractORB and
+        AssignFeaturesToGrid (src/Frame.cc:502-596): mvKeys stay as extracted, mvKeysUn are the
+        undistorted copies, the bounds come from the undistorted image corners."""
+        from . import _lib
+        d = np.zeros(5, np.float32)
+        d[:len(dist_coef)] = dist_coef
+        cam = _lib.Camera(*(float(v) for v in K), *(float(v) for v in d))
+        b = _lib.FrameBounds()
+        _lib.check(_lib.lib().orb_compute_image_bounds(int(rows), int(cols), cam, b))
+        f = cls(keypoints, descriptors, scale_factors, level_sigma2, K, (b.min_x, b.max_x, b.min_y, b.max_y), **kw)
+        f.mDistCoef = d
+        if d[0] != 0 and f.N:
+            xy = np.ascontiguousarray(np.stack([keypoints["x"], keypoints["y"]], 1), np.float32)
+            un = np.empty_like(xy)
+            _lib.check(_lib.lib().orb_undistort_points(int(device_id), f.N, _lib.ptr(xy), cam, _lib.ptr(un)))
+            f.mvKeysUn = keypoints.copy()
+            f.mvKeysUn["x"], f.mvKeysUn["y"] = un[:, 0], un[:, 1]
+        return f
+
     def ComputeBoW(self, vocabulary):
         """reference src/Frame.cc:483-497 / src/KeyFrame.cc:120-131: once per frame, levelsup 4"""
         if not self.mBowVec:
