@@ -239,11 +239,32 @@ struct MatchShared {
 // Frame::GetFeaturesInArea (reference src/Frame.cc:371-449) fused with the best /
 // second scan of the caller.  Visits candidates in the reference's order
 // (grid column, grid row, insertion order) and ranks them by (distance, visit order).
+// Largest distance at which a candidate can still change a decision of the replay: one
+// beyond the accept threshold is never matched, and as a second-best it weakens a match only
+// if nnratio * distance does not exceed the best one's distance, which is at most the
+// threshold.  Candidates beyond it are not ranked at all, so crowded windows of unrelated
+// descriptors (distance around 128) neither fill the kept lists nor cause new scans.
+template <int MODE>
+__device__ __forceinline__ int scan_dist_cap(const MatchArgs& A) {
+  auto with_ratio = [&](int th) {
+    if (!(A.nnratio > 0.f)) return 256;
+    const float c = (float)th / A.nnratio + 2.0f;
+    return c < 256.f ? (int)c : 256;
+  };
+  if (MODE == MODE_FRAMES) return TH_HIGH;
+  if (MODE == MODE_WINDOW) return A.max_dist;
+  if (MODE == MODE_MAPPOINTS) return with_ratio(TH_HIGH);
+  if (MODE == MODE_INIT) return with_ratio(TH_LOW);
+  if (MODE == MODE_BOW) return with_ratio(A.max_dist);
+  return 256;
+}
+
 template <int MODE>
 __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, int nt, const float4 geo,
                            const uint32_t* qd, int bucket0, int bucket1, float qx, float qy, Cand& c) {
   cand_init(c);
   const uint4* tdesc = S.tdesc;
+  const int dcap = scan_dist_cap<MODE>(A);
   (void)pair;
   if constexpr (!mode_bucketed(MODE)) {
     const float x = geo.x, y = geo.y, r = geo.z;
@@ -287,6 +308,7 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
           // (reference src/ORBmatcher.cc:596)
           if (S.occ[j] && (int)S.occ[j] - 1 <= d) continue;
         }
+        if (d > dcap) continue;
         cand_insert(c, ((uint32_t)d << 20) | (uint32_t)mypos, (uint32_t)j);
       }
     }
@@ -301,6 +323,7 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
       const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
       if constexpr (MODE == MODE_BOW) {
         // SearchByBoW keeps best and second over the whole bucket; the first minimum wins
+        if (d > dcap) continue;
         cand_insert(c, ((uint32_t)d << 20) | (uint32_t)pos, (uint32_t)j);
         continue;
       }
