@@ -191,21 +191,27 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
     w1[k] = valid[k] ? a1 : 0;
     w0[k] = valid[k] ? 2048 - a1 : 0;
   }
-  int hprev[4] = {0, 0, 0, 0};
+  // cv::resize's vertical step is ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16), rounded by
+  // (+2) >> 2 and saturated.  With the weight moved up 12 bits and the horizontal sum kept as
+  // (h >> 4) << 4 (both fit 24 bits) each product-and-shift is one v_mul_hi_u32_u24; the result
+  // never leaves 0..255 (the weights of a pair sum to 2048, or 2049 when both round up, and
+  // h <= 255 * 2049, so the two terms add up to at most 1020), so no clamp is needed.
+  auto mulhi24 = [](uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)) >> 32); };
+  uint32_t hprev[4] = {0, 0, 0, 0};
   int prev_row = -1;  // source row whose horizontal result is in hprev
   uint8_t* dst = pyr + (size_t)f * slab + Ld.off + c;
   const int rend = min(gy * PR_TR + PR_TR, Ld.h + 2 * kEdge);
   for (int r = gy * PR_TR; r < rend; r++) {
     const YTab ty = yt[refl101(r - kEdge, Ld.h)];
     const int s0 = ty.sy0, s1 = ty.sy1;
-    int h0[4], h1[4];
+    uint32_t h0[4], h1[4];
     if (s0 == prev_row) {
 #pragma unroll
       for (int k = 0; k < 4; k++) h0[k] = hprev[k];
     } else {
       const uint8_t* R = &s_src[(s0 - Y.x) * PR_SPITCH];
 #pragma unroll
-      for (int k = 0; k < 4; k++) h0[k] = R[col[k]] * w0[k] + R[col[k] + 1] * w1[k];
+      for (int k = 0; k < 4; k++) h0[k] = (uint32_t)(R[col[k]] * w0[k] + R[col[k] + 1] * w1[k]) & 0xFFFFF0u;
     }
     if (s1 == s0) {
 #pragma unroll
@@ -213,15 +219,14 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
     } else {
       const uint8_t* R = &s_src[(s1 - Y.x) * PR_SPITCH];
 #pragma unroll
-      for (int k = 0; k < 4; k++) h1[k] = R[col[k]] * w0[k] + R[col[k] + 1] * w1[k];
+      for (int k = 0; k < 4; k++) h1[k] = (uint32_t)(R[col[k]] * w0[k] + R[col[k] + 1] * w1[k]) & 0xFFFFF0u;
     }
-    const int b0 = ty.b0, b1 = ty.b1;
+    const uint32_t b0 = (uint32_t)ty.b0 << 12, b1 = (uint32_t)ty.b1 << 12;
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      int v = (((b0 * (h0[k] >> 4)) >> 16) + ((b1 * (h1[k] >> 4)) >> 16) + 2) >> 2;
-      v = min(max(v, 0), 255);
-      out |= (uint32_t)v << (8 * k);
+      const uint32_t v = (mulhi24(b0, h0[k]) + mulhi24(b1, h1[k]) + 2u) >> 2;
+      out |= v << (8 * k);
       hprev[k] = h1[k];
     }
     prev_row = s1;
