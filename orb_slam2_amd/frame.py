@@ -196,7 +196,10 @@ class KeyFrame(Frame):
         return (np.float32(1.0) / self.mvLevelSigma2).astype(np.float32)
 
     def IsInImage(self, x, y):
-        return self.mnMinX <= x < self.mnMaxX and self.mnMinY <= y < self.mnMaxY
+        """reference src/KeyFrame.cc:779-782; a KeyFrame keeps the frame's bounds as const int
+        (include/KeyFrame.h:411-414), i.e. truncated towards zero - only different from the
+        frame's own bounds when the camera has distortion"""
+        return int(self.mnMinX) <= x < int(self.mnMaxX) and int(self.mnMinY) <= y < int(self.mnMaxY)
 
     def GetRotation(self):
         return self.mTcw[:3, :3]
