@@ -52,3 +52,12 @@ def test_library_image_bounds_equal_oracle():
         want = oracle.image_bounds(rows, cols, K, d)
         assert (b.min_x, b.max_x, b.min_y, b.max_y) == tuple(np.float32(v) for v in want), (K, d)
     assert L.orb_compute_image_bounds(10, 10, _lib.Camera(0, 1, 0, 0, 0.1, 0, 0, 0, 0), b) == _lib.ERR_ARG
+
+
+def test_regression_vector_euroc():
+    """Bit patterns of the oracle's output for the EuRoC camera, recorded when the oracle was
+    written (pins the oracle against later edits; the reference itself holds no vectors)."""
+    pts = np.array([[0, 0], [752, 0], [0, 480], [752, 480], [100, 100], [600.5, 20.25]], np.float32)
+    want = np.array([[3272068015, 3266844893], [1147134072, 3266953218], [3271921288, 1141703142],
+                     [1147117037, 1141728102], [1113228145, 1117093491], [1143072551, 3251584121]], np.uint32)
+    assert np.array_equal(oracle.undistort_points(pts, EUROC_K, EUROC_D).view(np.uint32), want)
