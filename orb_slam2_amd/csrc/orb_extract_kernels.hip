@@ -301,10 +301,14 @@ __device__ __forceinline__ int fast_v1(const uint8_t* p /* centre in LDS */, int
 // neighbours' scores, where neighbours in another cell (hasL / hasR false) or on the
 // 3-px rim (V byte 0) count as 0.  Scores are V - 1, so "score > 0" is "V >= 2".
 __device__ __forceinline__ bool fast_nms_keep(const uint8_t* q, int v, bool hasL, bool hasR) {
-  bool keep = v > q[-F_PITCH] && v > q[F_PITCH];
-  if (hasL) keep = keep && v > q[-1] && v > q[-F_PITCH - 1] && v > q[F_PITCH - 1];
-  if (hasR) keep = keep && v > q[1] && v > q[-F_PITCH + 1] && v > q[F_PITCH + 1];
-  return keep;
+  // all eight loads first (the rim keeps them inside the map): one LDS round trip, not eight
+  const int u = q[-F_PITCH], d = q[F_PITCH];
+  const int l0 = q[-1], l1 = q[-F_PITCH - 1], l2 = q[F_PITCH - 1];
+  const int r0 = q[1], r1 = q[-F_PITCH + 1], r2 = q[F_PITCH + 1];
+  const int mc = max(u, d);
+  const int ml = hasL ? max(l0, max(l1, l2)) : 0;
+  const int mr = hasR ? max(r0, max(r1, r2)) : 0;
+  return v > max(mc, max(ml, mr));
 }
 
 __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
