@@ -286,27 +286,34 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
     // array, so a column of the window is one contiguous run of items
     for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
       const int pe = S.start[ix * GRID_ROWS + nMaxCellY + 1];
-      for (int p = S.start[ix * GRID_ROWS + nMinCellY]; p < pe; p++) {
-        const int j = S.items[p];
+      int p = S.start[ix * GRID_ROWS + nMinCellY];
+      int jn = p < pe ? (int)S.items[p] : 0;
+      while (p < pe) {
+        const int j = jn;
+        p++;
+        jn = p < pe ? (int)S.items[p] : 0;  // the next item is on its way while this one is tested
+        // everything the tests read, in one LDS round trip
+        const int oct = S.koct[j], occ = S.occ[j];
+        const float kxj = S.kx[j], kyj = S.ky[j];
         if (bCheckLevels) {
-          if ((int)S.koct[j] < minLevel) continue;
-          if (maxLevel >= 0 && (int)S.koct[j] > maxLevel) continue;
+          if (oct < minLevel) continue;
+          if (maxLevel >= 0 && oct > maxLevel) continue;
         }
-        if (!(fabsf(S.kx[j] - x) < r && fabsf(S.ky[j] - y) < r)) continue;
+        if (!(fabsf(kxj - x) < r && fabsf(kyj - y) < r)) continue;
         const int mypos = pos++;
-        if (MODE != MODE_INIT && S.occ[j]) continue;
+        if (MODE != MODE_INIT && occ) continue;
         if constexpr (MODE == MODE_BEST) {
           if (A.chi2 > 0) {  // reference src/ORBmatcher.cc:1158-1164
-            const float ex = x - S.kx[j], ey = y - S.ky[j];
+            const float ex = x - kxj, ey = y - kyj;
             const float e2 = ex * ex + ey * ey;
-            if ((double)(e2 * A.sigma2[min((int)S.koct[j], kMaxLevels - 1)]) > A.chi2) continue;
+            if ((double)(e2 * A.sigma2[min(oct, kMaxLevels - 1)]) > A.chi2) continue;
           }
         }
         const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
         if constexpr (MODE == MODE_INIT) {
           // occ = matched distance + 1 (0 = never matched): skip if vMatchedDistance[i2] <= dist
           // (reference src/ORBmatcher.cc:596)
-          if (S.occ[j] && (int)S.occ[j] - 1 <= d) continue;
+          if (occ && occ - 1 <= d) continue;
         }
         if (d > dcap) continue;
         cand_insert(c, ((uint32_t)d << 20) | (uint32_t)mypos, (uint32_t)j);
