@@ -26,38 +26,62 @@ __device__ __forceinline__ int refl101(int i, int n) {
 // of 4), so interior pieces are read as five aligned dwords and shifted into place;
 // pieces that touch the frame or the row ends go byte by byte.
 // ---------------------------------------------------------------------------
+constexpr int L0_PIECES = 2;  // 16-byte pieces per thread of the level-0 copy
 __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restrict__ img, size_t stride,
                                                          size_t frame_stride, uint8_t* __restrict__ pyr,
                                                          unsigned long long slab, LevelGeom L) {
+  // a thread moves L0_PIECES pieces a fixed distance apart; all their loads are issued before
+  // the first result is needed, so that more bytes are in flight per wavefront
   const int nchunk = L.pitch >> 4;
-  const int t = blockIdx.y * 256 + threadIdx.x;
-  const int row = t / nchunk;  // padded row
-  if (row >= L.h + 2 * kEdge) return;
-  const int c16 = (t - row * nchunk) * 16;
+  const int total = nchunk * (L.h + 2 * kEdge);
+  const int half = (total + L0_PIECES - 1) / L0_PIECES;
+  const int t0 = blockIdx.y * 256 + threadIdx.x;
+  if (t0 >= half) return;
   const int f = blockIdx.x;
-  const int iy = refl101(row - kEdge, L.h);
-  const uint8_t* S = img + (size_t)f * frame_stride + (size_t)iy * stride;
-  const int px0 = c16 - kXOff;
-  uint4 out;
-  if (px0 >= 4 && px0 + 20 <= L.w) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(S + px0);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3);
-    const uint32_t x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3], x4 = q[4];
-    out.x = __builtin_amdgcn_alignbyte(x1, x0, sh);
-    out.y = __builtin_amdgcn_alignbyte(x2, x1, sh);
-    out.z = __builtin_amdgcn_alignbyte(x3, x2, sh);
-    out.w = __builtin_amdgcn_alignbyte(x4, x3, sh);
-  } else {
-    uint32_t o[4] = {0, 0, 0, 0};
+  uint32_t x[L0_PIECES][5];
+  const uint8_t* S[L0_PIECES];
+  int px0[L0_PIECES], row[L0_PIECES], c16[L0_PIECES];
+  bool live[L0_PIECES], fastp[L0_PIECES];
+  uint32_t sh[L0_PIECES];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int px = px0 + k;
-      if (px >= -kEdge && px < L.w + kEdge) o[k >> 2] |= (uint32_t)S[refl101(px, L.w)] << (8 * (k & 3));
+  for (int u = 0; u < L0_PIECES; u++) {
+    const int t = t0 + u * half;
+    live[u] = t < total;
+    const int tt = live[u] ? t : 0;
+    row[u] = tt / nchunk;  // padded row
+    c16[u] = (tt - row[u] * nchunk) * 16;
+    const int iy = refl101(row[u] - kEdge, L.h);
+    S[u] = img + (size_t)f * frame_stride + (size_t)iy * stride;
+    px0[u] = c16[u] - kXOff;
+    fastp[u] = px0[u] >= 4 && px0[u] + 20 <= L.w;
+    if (fastp[u]) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>(S[u] + px0[u]);
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+      sh[u] = (uint32_t)(a & 3);
+#pragma unroll
+      for (int k = 0; k < 5; k++) x[u][k] = q[k];
     }
-    out = make_uint4(o[0], o[1], o[2], o[3]);
   }
-  *reinterpret_cast<uint4*>(pyr + (size_t)f * slab + L.off + (size_t)row * L.pitch + c16) = out;
+#pragma unroll
+  for (int u = 0; u < L0_PIECES; u++) {
+    if (!live[u]) continue;
+    uint4 out;
+    if (fastp[u]) {
+      out.x = __builtin_amdgcn_alignbyte(x[u][1], x[u][0], sh[u]);
+      out.y = __builtin_amdgcn_alignbyte(x[u][2], x[u][1], sh[u]);
+      out.z = __builtin_amdgcn_alignbyte(x[u][3], x[u][2], sh[u]);
+      out.w = __builtin_amdgcn_alignbyte(x[u][4], x[u][3], sh[u]);
+    } else {
+      uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int px = px0[u] + k;
+        if (px >= -kEdge && px < L.w + kEdge) o[k >> 2] |= (uint32_t)S[u][refl101(px, L.w)] << (8 * (k & 3));
+      }
+      out = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    *reinterpret_cast<uint4*>(pyr + (size_t)f * slab + L.off + (size_t)row[u] * L.pitch + c16[u]) = out;
+  }
 }
 
 // Level 0 from an interleaved colour image: cv::cvtColor(..., CV_RGB2GRAY / CV_BGR2GRAY /
@@ -1302,7 +1326,8 @@ void launch_pyr_level0(const uint8_t* img, size_t stride, size_t frame_stride, u
                        int nframes, hipStream_t st) {
   const LevelGeom& L = P.lv[0];
   const int pieces = (L.pitch / 16) * (L.h + 2 * kEdge);
-  dim3 grid(nframes, (pieces + 255) / 256);
+  const int per_thread = (pieces + L0_PIECES - 1) / L0_PIECES;
+  dim3 grid(nframes, (per_thread + 255) / 256);
   hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L);
 }
 void launch_pyr_level0_color(const uint8_t* img, size_t stride, size_t frame_stride, int channels, bool rgb_order,
