@@ -341,6 +341,13 @@ int orb_search_for_triangulation(
 int orb_knn2_device(int device_id, const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db,
                     int db_index_base, float ratio, int* d_best, int* d_second, int* d_idx,
                     uint8_t* d_accept, void* stream);
+/* The same search with the kernel chosen explicitly: 0 = as orb_knn2_device chooses,
+ * 1 = popcount on the vector units, 2 = matrix cores (bits as +1 / -1 int8, distance =
+ * (256 - dot product) / 2).  Both give identical results; the choice exists for tests and
+ * measurements.  No counterpart in the reference. */
+int orb_knn2_device_algo(int device_id, const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db,
+                         int db_index_base, float ratio, int* d_best, int* d_second, int* d_idx,
+                         uint8_t* d_accept, void* stream, int algo);
 /* Merge of per-shard kNN-2 results (shards in ascending database order):
  * in arrays are [n_shards][n_q]; the merged result equals a single scan of the
  * concatenated database.  Device pointers. */

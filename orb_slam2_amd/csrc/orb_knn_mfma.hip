@@ -1,0 +1,169 @@
+// Brute-force Hamming kNN-2 on the matrix cores of gfx950.
+//
+// With every descriptor bit b mapped to s = 2b - 1 (+1 / -1 as int8), the dot product of two
+// descriptors is (#equal bits) - (#different bits) = 256 - 2 * hamming, an exact integer.  So
+// the 1M x 1M distance table is an int8 GEMM with K = 256, which v_mfma_i32_32x32x32_i8 does at
+// 1024 multiply-adds per cycle and SIMD - the popcount form needs 16 vector instructions per
+// pair.  Results are the same integers as the popcount kernel's (orb_match.hip: knn2_kernel),
+// including the tie rule (first minimum = lowest database row).
+//
+// Work decomposition: a wavefront owns KM_QT tiles of 32 queries as the B operand, expanded
+// once into registers (KM_QT * 8 K-steps * 16 bytes per lane).  Database rows stream through
+// LDS 32 at a time: the workgroup expands the packed 32 x 32 bytes to 32 x 256 int8 (double
+// buffered, one barrier per tile) in the fragment order of the A operand, every wavefront
+// reads the eight A fragments (one ds_read_b128 each) and issues 8 * KM_QT MFMAs.  In the
+// 32x32 result a lane holds one query (column) and 16 database rows; it keeps the two
+// smallest (distance, row) keys of its rows, lanes l and l + 32 (same query, other rows) are
+// merged at the end.  Rows arrive in ascending order, so after the first few thousand a tile
+// almost never changes any lane's two best: the update is skipped for the whole wavefront
+// unless some accumulator exceeds the lane's second-best dot product.
+#include "orb_common.h"
+
+namespace orbhip {
+namespace {
+
+typedef int km_v4i __attribute__((ext_vector_type(4)));
+typedef int km_v16i __attribute__((ext_vector_type(16)));
+
+constexpr int KM_THREADS = 256;        // 4 wavefronts
+constexpr int KM_QT = 3;               // query tiles (of 32) per wavefront
+constexpr int KM_QPW = 32 * KM_QT;     // queries per wavefront
+constexpr int KM_QPB = KM_QPW * (KM_THREADS / 64);
+constexpr int KM_ROWBITS = 21;         // key = (256 - dot) << 21 | row; 256 - dot = 2 * distance <= 512
+constexpr int KM_CHUNK = 1 << KM_ROWBITS;
+
+// 16 descriptor bits -> 16 bytes of +1 (bit set) / -1, byte i of dword d = bit 4d + i
+__device__ __forceinline__ km_v4i expand16(uint32_t bits, bool valid) {
+  km_v4i r;
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    const uint32_t x = (bits >> (4 * d)) & 15u;
+    const uint32_t m = (x * 0x00204081u) & 0x01010101u;  // bit i -> bit 0 of byte i
+    const uint32_t v = ~((m << 8) - (m << 1));           // byte: 0x01 where set, 0xFF where clear
+    r[d] = valid ? (int)v : 0;                           // rows past the end contribute dot = 0 and are skipped by index
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* __restrict__ q16, int nq,
+                                                              const uint16_t* __restrict__ db16, int ndb, int index_base,
+                                                              float ratio, int* __restrict__ out_best,
+                                                              int* __restrict__ out_second, int* __restrict__ out_idx,
+                                                              uint8_t* __restrict__ out_accept) {
+  // A fragments of one 32-row tile: [group g = 2 * kstep + half][row][16 bytes], two buffers
+  __shared__ __attribute__((aligned(16))) km_v4i s_a[2][16 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int qbase = blockIdx.x * KM_QPB + wave * KM_QPW;
+
+  // B operand: the wave's queries, expanded once.  Lane (r, h) holds for tile t and K-step s
+  // the 16 bits 32 s + 16 h .. + 15 of query qbase + 32 t + r - the same bit -> k order as the
+  // A fragments below, which is all the dot product needs.
+  km_v4i b[KM_QT][8];
+#pragma unroll
+  for (int t = 0; t < KM_QT; t++) {
+    const int qi = min(qbase + 32 * t + r, nq - 1);
+#pragma unroll
+    for (int s = 0; s < 8; s++) b[t][s] = expand16(q16[(size_t)qi * 16 + 2 * s + h], true);
+  }
+  int bd[KM_QT], sd[KM_QT], bi[KM_QT];
+#pragma unroll
+  for (int t = 0; t < KM_QT; t++) { bd[t] = 256; sd[t] = 256; bi[t] = -1; }
+
+  // the two work items (row, group) of this thread in the expansion of a tile
+  const int er = tid & 31, eg0 = tid >> 5;  // groups eg0 and eg0 + 8
+  const km_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  for (int cbase = 0; cbase < ndb; cbase += KM_CHUNK) {
+    const int cn = min(KM_CHUNK, ndb - cbase);
+    const int ntiles = (cn + 31) >> 5;
+    uint32_t k1[KM_QT], k2[KM_QT];
+    int thr[KM_QT];  // an accumulator must exceed this to change (k1, k2)
+#pragma unroll
+    for (int t = 0; t < KM_QT; t++) { k1[t] = 0xFFFFFFFFu; k2[t] = 0xFFFFFFFFu; thr[t] = -100000; }
+    uint32_t pk0 = 0, pk1 = 0;
+    auto fetch = [&](int tile) {
+      const int row = tile * 32 + er;
+      const bool v = row < cn;
+      const size_t o = (size_t)(cbase + (v ? row : 0)) * 16;
+      pk0 = db16[o + eg0];
+      pk1 = db16[o + eg0 + 8];
+    };
+    fetch(0);
+    for (int tile = 0; tile < ntiles; tile++) {
+      const bool v = tile * 32 + er < cn;
+      km_v4i* buf = s_a[tile & 1];
+      buf[eg0 * 32 + er] = expand16(pk0, v);
+      buf[(eg0 + 8) * 32 + er] = expand16(pk1, v);
+      __syncthreads();
+      if (tile + 1 < ntiles) fetch(tile + 1);  // in flight during the MFMAs
+      km_v16i acc[KM_QT];
+#pragma unroll
+      for (int s = 0; s < 8; s++) {
+        const km_v4i a = buf[(2 * s + h) * 32 + r];
+#pragma unroll
+        for (int t = 0; t < KM_QT; t++)
+          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[t][s], s == 0 ? zero : acc[t], 0, 0, 0);
+      }
+      // acc[t][j] = dot(query of this lane in tile t, database row tile * 32 + (j & 3) + 8 * (j >> 2) + 4 h)
+      const int row0 = tile * 32 + 4 * h;
+#pragma unroll
+      for (int t = 0; t < KM_QT; t++) {
+        int m = acc[t][0];
+#pragma unroll
+        for (int j = 1; j < 16; j++) m = max(m, acc[t][j]);
+        if (__builtin_amdgcn_ballot_w64(m > thr[t]) != 0) {
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            const int row = row0 + (j & 3) + 8 * (j >> 2);
+            const uint32_t key = row < cn ? ((uint32_t)(256 - acc[t][j]) << KM_ROWBITS) | (uint32_t)row : 0xFFFFFFFFu;
+            // two smallest keys: k1 <= k2 always, so the new second is the median of the three
+            const uint32_t lo = min(k1[t], key);
+            k2[t] = max(min(k2[t], key), min(max(k1[t], key), k2[t]));
+            k1[t] = lo;
+          }
+          thr[t] = k2[t] == 0xFFFFFFFFu ? -100000 : 256 - (int)(k2[t] >> KM_ROWBITS);
+        }
+      }
+    }
+    __syncthreads();  // the next chunk starts writing buffer 0 again
+    // lanes l and l + 32 hold the same queries over different rows
+#pragma unroll
+    for (int t = 0; t < KM_QT; t++) {
+      const uint32_t o1 = (uint32_t)__shfl_xor((int)k1[t], 32, 64), o2 = (uint32_t)__shfl_xor((int)k2[t], 32, 64);
+      const uint32_t m1 = min(k1[t], o1);
+      const uint32_t m2 = min(max(k1[t], o1), min(k2[t], o2));
+      // fold the chunk into the running (best, second, index): an earlier chunk keeps ties
+      const int cb = m1 == 0xFFFFFFFFu ? 256 : (int)(m1 >> (KM_ROWBITS + 1));
+      const int cs = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> (KM_ROWBITS + 1));
+      const int ci = (int)(m1 & (KM_CHUNK - 1)) + cbase;
+      if (cb < bd[t]) { sd[t] = min(bd[t], cs); bd[t] = cb; bi[t] = ci; }
+      else sd[t] = min(sd[t], cb);
+    }
+  }
+  if (h == 0) {
+#pragma unroll
+    for (int t = 0; t < KM_QT; t++) {
+      const int qi = qbase + 32 * t + r;
+      if (qi < nq) {
+        out_best[qi] = bd[t];
+        out_second[qi] = sd[t];
+        out_idx[qi] = bi[t] < 0 ? -1 : bi[t] + index_base;
+        if (out_accept) out_accept[qi] = (uint8_t)(bi[t] >= 0 && (float)bd[t] < __fmul_rn(ratio, (float)sd[t]));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_knn2_mfma(const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db, int index_base, float ratio,
+                            int* d_best, int* d_second, int* d_idx, uint8_t* d_accept, hipStream_t st) {
+  hipLaunchKernelGGL(knn2_mfma_kernel, dim3((n_q + KM_QPB - 1) / KM_QPB), dim3(KM_THREADS), 0, st,
+                     reinterpret_cast<const uint16_t*>(d_q), n_q, reinterpret_cast<const uint16_t*>(d_db), n_db,
+                     index_base, ratio, d_best, d_second, d_idx, d_accept);
+  return hipGetLastError();
+}
+int knn2_mfma_queries_per_block() { return KM_QPB; }
+
+}  // namespace orbhip

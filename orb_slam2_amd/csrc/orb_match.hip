@@ -12,6 +12,8 @@
 #include "orb_common.h"
 
 namespace orbhip {
+hipError_t launch_knn2_mfma(const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db, int index_base, float ratio,
+                            int* d_best, int* d_second, int* d_idx, uint8_t* d_accept, hipStream_t st);
 
 constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher.cc:41-43
 constexpr int GRID_COLS = 64, GRID_ROWS = 48;                 // reference include/Frame.h:47,52
@@ -967,18 +969,32 @@ int orb_hamming_distance_pairs(int device_id, const uint8_t* a, const uint8_t* b
   return ORBHIP_OK;
 }
 
-int orb_knn2_device(int device_id, const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db, int db_index_base,
-                    float ratio, int* d_best, int* d_second, int* d_idx, uint8_t* d_accept, void* stream) {
+int orb_knn2_device_algo(int device_id, const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db, int db_index_base,
+                         float ratio, int* d_best, int* d_second, int* d_idx, uint8_t* d_accept, void* stream, int algo) {
   if (n_q <= 0) return ORBHIP_OK;
   if (!d_q || !d_best || !d_second || !d_idx || (n_db > 0 && !d_db) || n_db < 0) { set_error("null argument"); return ORBHIP_ERR_ARG; }
   if (((uintptr_t)d_q | (uintptr_t)d_db) & 15) { set_error("descriptor arrays must be 16-byte aligned"); return ORBHIP_ERR_ARG; }
+  if (algo < 0 || algo > 2) { set_error("algo must be 0 (auto), 1 (popcount) or 2 (matrix cores)"); return ORBHIP_ERR_ARG; }
   DevSel g(device_id);
+  // the matrix-core kernel pays off once a workgroup's 512 queries meet a few thousand rows
+  const bool mfma = algo == 2 || (algo == 0 && n_db >= 2048 && n_q >= 256);
+  if (mfma && n_db > 0) {
+    ORB_HIP_CHECK(launch_knn2_mfma(d_q, n_q, d_db, n_db, db_index_base, ratio, d_best, d_second, d_idx, d_accept,
+                                   (hipStream_t)stream));
+    return ORBHIP_OK;
+  }
   const int per_block = KNN_THREADS * KNN_KQ;
   hipLaunchKernelGGL(knn2_kernel, dim3((n_q + per_block - 1) / per_block), dim3(KNN_THREADS), 0, (hipStream_t)stream,
                      (const uint4*)d_q, n_q, (const uint4*)d_db, n_db, db_index_base, ratio, d_best, d_second, d_idx,
                      d_accept);
   ORB_HIP_CHECK(hipGetLastError());
   return ORBHIP_OK;
+}
+
+int orb_knn2_device(int device_id, const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db, int db_index_base,
+                    float ratio, int* d_best, int* d_second, int* d_idx, uint8_t* d_accept, void* stream) {
+  return orb_knn2_device_algo(device_id, d_q, n_q, d_db, n_db, db_index_base, ratio, d_best, d_second, d_idx, d_accept,
+                              stream, 0);
 }
 
 int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_best, const int* d_second,

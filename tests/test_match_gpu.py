@@ -685,3 +685,36 @@ def test_search_for_initialization(oracle, seed, n, win, ratio, ori):
     assert wn > 100, "scene too poor"
     hit = w12 >= 0
     assert np.array_equal(prev[hit, 0], x2[w12[hit]]) and np.array_equal(prev[~hit], prev0[~hit])
+
+
+@pytest.mark.parametrize("nq,ndb,seed", [(1, 1, 0), (37, 5, 1), (512, 2048, 2), (513, 2079, 3), (1000, 33, 4),
+                                          (3000, 10000, 5), (64, 70001, 6)])
+def test_knn2_matrix_core_kernel_equals_popcount_kernel(oracle, nq, ndb, seed):
+    """The two kNN-2 kernels (vector popcount / int8 matrix cores) return the same integers,
+    ties included, and both equal the oracle."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from orb_slam2_amd import _lib
+    rng = np.random.default_rng(seed)
+    db = rng.integers(0, 256, (ndb, 32), dtype=np.uint8)
+    if ndb > 8:
+        db[ndb // 2] = db[1]            # exact duplicates: the lower row must win
+        db[ndb - 1] = db[0]
+    q = db[rng.integers(0, ndb, nq)].copy()
+    flips = rng.integers(0, 2, nq).astype(bool)
+    q[flips] = flip_bits(rng, q[flips], 40) if flips.any() else q[flips]
+    q[::7] = rng.integers(0, 256, (len(q[::7]), 32), dtype=np.uint8)
+    d_q, d_db = torch.from_numpy(q).cuda(), torch.from_numpy(db).cuda()
+    outs = []
+    for algo in (1, 2):
+        res = torch.full((3, nq), -7, dtype=torch.int32, device="cuda")
+        acc = torch.zeros(nq, dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().orb_knn2_device_algo(0, C.c_void_p(d_q.data_ptr()), nq, C.c_void_p(d_db.data_ptr()), ndb, 1000, 0.7,
+                                                   C.c_void_p(res[0].data_ptr()), C.c_void_p(res[1].data_ptr()),
+                                                   C.c_void_p(res[2].data_ptr()), C.c_void_p(acc.data_ptr()), None, algo))
+        torch.cuda.synchronize()
+        outs.append((res.cpu().numpy(), acc.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    wb, ws, wi, wa = oracle.knn2_bruteforce(q, db, 0.7)
+    assert np.array_equal(outs[1][0][0], wb) and np.array_equal(outs[1][0][1], ws)
+    assert np.array_equal(outs[1][0][2], wi + 1000) and np.array_equal(outs[1][1], wa)
