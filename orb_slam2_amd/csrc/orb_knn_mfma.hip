@@ -9,8 +9,9 @@
 //
 // Work decomposition: a wavefront owns KM_QT tiles of 32 queries as the B operand, expanded
 // once into registers (KM_QT * 8 K-steps * 16 bytes per lane).  Database rows stream through
-// LDS 32 at a time: the workgroup expands the packed 32 x 32 bytes to 32 x 256 int8 (double
-// buffered, one barrier per tile) in the fragment order of the A operand, every wavefront
+// LDS 32 at a time: the workgroup expands the packed 32 x 32 bytes to 32 x 256 int8 (through a
+// byte -> 8 bytes table in LDS; double buffered, one barrier per tile) in the fragment order of
+// the A operand, every wavefront
 // reads the eight A fragments (one ds_read_b128 each) and issues 8 * KM_QT MFMAs.  In the
 // 32x32 result a lane holds one query (column) and 16 database rows; it keeps the two
 // smallest (distance, row) keys of its rows, lanes l and l + 32 (same query, other rows) are
@@ -26,21 +27,25 @@ typedef int km_v4i __attribute__((ext_vector_type(4)));
 typedef int km_v16i __attribute__((ext_vector_type(16)));
 
 constexpr int KM_THREADS = 256;        // 4 wavefronts
-constexpr int KM_QT = 3;               // query tiles (of 32) per wavefront
+constexpr int KM_QT = 4;               // query tiles (of 32) per wavefront
 constexpr int KM_QPW = 32 * KM_QT;     // queries per wavefront
 constexpr int KM_QPB = KM_QPW * (KM_THREADS / 64);
 constexpr int KM_ROWBITS = 21;         // key = (256 - dot) << 21 | row; 256 - dot = 2 * distance <= 512
 constexpr int KM_CHUNK = 1 << KM_ROWBITS;
 
-// 16 descriptor bits -> 16 bytes of +1 (bit set) / -1, byte i of dword d = bit 4d + i
+// 16 descriptor bits -> 16 bytes of +1 (bit set) / -1, byte i of dword d = bit 4d + i.
+// The multiplication puts bit i of a nibble at bit 2 of byte i, i.e. a v_perm selector byte of
+// 4 (first byte of 0x01010101) or 0 (first byte of 0xFFFFFFFF); rows past the end of the
+// database get selector 0x0c everywhere (constant 0): their dot products are 0 and they are
+// skipped by index.
 __device__ __forceinline__ km_v4i expand16(uint32_t bits, bool valid) {
+  const uint32_t off = valid ? 0u : 0x0c0c0c0cu;
   km_v4i r;
 #pragma unroll
   for (int d = 0; d < 4; d++) {
     const uint32_t x = (bits >> (4 * d)) & 15u;
-    const uint32_t m = (x * 0x00204081u) & 0x01010101u;  // bit i -> bit 0 of byte i
-    const uint32_t v = ~((m << 8) - (m << 1));           // byte: 0x01 where set, 0xFF where clear
-    r[d] = valid ? (int)v : 0;                           // rows past the end contribute dot = 0 and are skipped by index
+    const uint32_t sel = ((x * 0x00810204u) & 0x04040404u) | off;
+    r[d] = (int)__builtin_amdgcn_perm(0x01010101u, 0xFFFFFFFFu, sel);
   }
   return r;
 }
@@ -52,10 +57,17 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
                                                               uint8_t* __restrict__ out_accept) {
   // A fragments of one 32-row tile: [group g = 2 * kstep + half][row][16 bytes], two buffers
   __shared__ __attribute__((aligned(16))) km_v4i s_a[2][16 * 32];
+  // 8 descriptor bits -> 8 bytes of +1 / -1; entry 256 (all zero) stands for rows past the end
+  __shared__ __attribute__((aligned(8))) uint2 s_lut[257];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int qbase = blockIdx.x * KM_QPB + wave * KM_QPW;
 
+  for (int i = tid; i < 257; i += KM_THREADS) {
+    const km_v4i e = expand16((uint32_t)i, i < 256);
+    s_lut[i] = make_uint2((uint32_t)e[0], (uint32_t)e[1]);
+  }
+  __syncthreads();
   // B operand: the wave's queries, expanded once.  Lane (r, h) holds for tile t and K-step s
   // the 16 bits 32 s + 16 h .. + 15 of query qbase + 32 t + r - the same bit -> k order as the
   // A fragments below, which is all the dot product needs.
@@ -93,8 +105,12 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
     for (int tile = 0; tile < ntiles; tile++) {
       const bool v = tile * 32 + er < cn;
       km_v4i* buf = s_a[tile & 1];
-      buf[eg0 * 32 + er] = expand16(pk0, v);
-      buf[(eg0 + 8) * 32 + er] = expand16(pk1, v);
+      {
+        const uint2 a0 = s_lut[v ? (pk0 & 255u) : 256u], a1 = s_lut[v ? (pk0 >> 8) : 256u];
+        const uint2 c0 = s_lut[v ? (pk1 & 255u) : 256u], c1 = s_lut[v ? (pk1 >> 8) : 256u];
+        buf[eg0 * 32 + er] = km_v4i{(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
+        buf[(eg0 + 8) * 32 + er] = km_v4i{(int)c0.x, (int)c0.y, (int)c1.x, (int)c1.y};
+      }
       __syncthreads();
       if (tile + 1 < ntiles) fetch(tile + 1);  // in flight during the MFMAs
       km_v16i acc[KM_QT];
@@ -113,9 +129,11 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
 #pragma unroll
         for (int j = 1; j < 16; j++) m = max(m, acc[t][j]);
         if (__builtin_amdgcn_ballot_w64(m > thr[t]) != 0) {
+          int rbase = row0;
+          asm volatile("" : "+v"(rbase));  // keeps the 16 row indices out of the registers of the common path
 #pragma unroll
           for (int j = 0; j < 16; j++) {
-            const int row = row0 + (j & 3) + 8 * (j >> 2);
+            const int row = rbase + (j & 3) + 8 * (j >> 2);
             const uint32_t key = row < cn ? ((uint32_t)(256 - acc[t][j]) << KM_ROWBITS) | (uint32_t)row : 0xFFFFFFFFu;
             // two smallest keys: k1 <= k2 always, so the new second is the median of the three
             const uint32_t lo = min(k1[t], key);
