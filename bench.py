@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 ROWS, COLS, NFEAT, NLEVELS = 376, 1241, 2000, 8
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 VALU_PEAK_LANEOPS = 256 * 64 * 2.4e9  # CUs x lanes x clock: peak 32-bit integer lane-ops/s
+MFMA_I8_PEAK_OPS = 2 * 1024 * 1024 * 2.4e9  # 2 x (SIMDs x int8 multiply-adds per cycle x clock): dense int8 peak
 
 
 def level_sizes(rows, cols, nlevels=8, f=1.2):
@@ -200,10 +201,19 @@ def main():
         pairs = float(nq) * float(ndb)
         knn = {"n_query": nq, "n_database": ndb, "ratio": 0.7, "seconds": round(tk, 4),
                "matches_per_s": round(nq / tk, 1), "pairs_per_s": round(pairs / tk, 1),
-               "accepted": int(acc.sum().item()),
-               "valu": {"lane_ops_per_pair": 16, "achieved_laneops_per_s": round(16 * pairs / tk, 1),
-                        "peak_laneops_per_s": world * VALU_PEAK_LANEOPS,
-                        "frac": round(16 * pairs / tk / (world * VALU_PEAK_LANEOPS), 4)}}
+               "accepted": int(acc.sum().item())}
+        if hi - lo >= 2048 and nq >= 256:
+            # the matrix-core kernel: one descriptor pair = 256 int8 multiply-adds
+            knn["kernel"] = "knn2_mfma_kernel"
+            knn["roofline"] = {"bound": "mfma", "achieved": round(512 * pairs / tk / 1e12, 1),
+                               "peak": round(world * MFMA_I8_PEAK_OPS / 1e12, 1), "unit": "TOP/s",
+                               "frac": round(512 * pairs / tk / (world * MFMA_I8_PEAK_OPS), 4)}
+        else:
+            # the popcount kernel: 16 vector instructions per pair
+            knn["kernel"] = "knn2_kernel"
+            knn["roofline"] = {"bound": "valu", "achieved": round(16 * pairs / tk / 1e12, 2),
+                               "peak": round(world * VALU_PEAK_LANEOPS / 1e12, 2), "unit": "T lane-ops/s",
+                               "frac": round(16 * pairs / tk / (world * VALU_PEAK_LANEOPS), 4)}
 
     # ---------------- CPU baseline (oracle, one core, rank 0, bounded sample) ----------------
     cpu = None

@@ -30,6 +30,7 @@ constexpr int KM_THREADS = 256;        // 4 wavefronts
 constexpr int KM_QT = 4;               // query tiles (of 32) per wavefront
 constexpr int KM_QPW = 32 * KM_QT;     // queries per wavefront
 constexpr int KM_QPB = KM_QPW * (KM_THREADS / 64);
+constexpr int KM_SUB = 1;               // 32-row tiles expanded per barrier (2 measured the same)
 constexpr int KM_ROWBITS = 21;         // key = (256 - dot) << 21 | row; 256 - dot = 2 * distance <= 512
 constexpr int KM_CHUNK = 1 << KM_ROWBITS;
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
                                                               int* __restrict__ out_second, int* __restrict__ out_idx,
                                                               uint8_t* __restrict__ out_accept) {
   // A fragments of one 32-row tile: [group g = 2 * kstep + half][row][16 bytes], two buffers
-  __shared__ __attribute__((aligned(16))) km_v4i s_a[2][16 * 32];
+  __shared__ __attribute__((aligned(16))) km_v4i s_a[2][KM_SUB][16 * 32];
   // 8 descriptor bits -> 8 bytes of +1 / -1; entry 256 (all zero) stands for rows past the end
   __shared__ __attribute__((aligned(8))) uint2 s_lut[257];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,59 +89,66 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
 
   for (int cbase = 0; cbase < ndb; cbase += KM_CHUNK) {
     const int cn = min(KM_CHUNK, ndb - cbase);
-    const int ntiles = (cn + 31) >> 5;
+    const int ntiles = (cn + 32 * KM_SUB - 1) / (32 * KM_SUB);  // tiles of 32 * KM_SUB rows
     uint32_t k1[KM_QT], k2[KM_QT];
     int thr[KM_QT];  // an accumulator must exceed this to change (k1, k2)
 #pragma unroll
     for (int t = 0; t < KM_QT; t++) { k1[t] = 0xFFFFFFFFu; k2[t] = 0xFFFFFFFFu; thr[t] = -100000; }
-    uint32_t pk0 = 0, pk1 = 0;
+    uint32_t pk[KM_SUB][2];
     auto fetch = [&](int tile) {
-      const int row = tile * 32 + er;
-      const bool v = row < cn;
-      const size_t o = (size_t)(cbase + (v ? row : 0)) * 16;
-      pk0 = db16[o + eg0];
-      pk1 = db16[o + eg0 + 8];
+#pragma unroll
+      for (int u = 0; u < KM_SUB; u++) {
+        const int row = (tile * KM_SUB + u) * 32 + er;
+        const size_t o = (size_t)(cbase + (row < cn ? row : 0)) * 16;
+        pk[u][0] = db16[o + eg0];
+        pk[u][1] = db16[o + eg0 + 8];
+      }
     };
     fetch(0);
     for (int tile = 0; tile < ntiles; tile++) {
-      const bool v = tile * 32 + er < cn;
-      km_v4i* buf = s_a[tile & 1];
-      {
-        const uint2 a0 = s_lut[v ? (pk0 & 255u) : 256u], a1 = s_lut[v ? (pk0 >> 8) : 256u];
-        const uint2 c0 = s_lut[v ? (pk1 & 255u) : 256u], c1 = s_lut[v ? (pk1 >> 8) : 256u];
+#pragma unroll
+      for (int u = 0; u < KM_SUB; u++) {
+        const bool v = (tile * KM_SUB + u) * 32 + er < cn;
+        km_v4i* buf = s_a[tile & 1][u];
+        const uint2 a0 = s_lut[v ? (pk[u][0] & 255u) : 256u], a1 = s_lut[v ? (pk[u][0] >> 8) : 256u];
+        const uint2 c0 = s_lut[v ? (pk[u][1] & 255u) : 256u], c1 = s_lut[v ? (pk[u][1] >> 8) : 256u];
         buf[eg0 * 32 + er] = km_v4i{(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
         buf[(eg0 + 8) * 32 + er] = km_v4i{(int)c0.x, (int)c0.y, (int)c1.x, (int)c1.y};
       }
       __syncthreads();
       if (tile + 1 < ntiles) fetch(tile + 1);  // in flight during the MFMAs
-      km_v16i acc[KM_QT];
 #pragma unroll
-      for (int s = 0; s < 8; s++) {
-        const km_v4i a = buf[(2 * s + h) * 32 + r];
+      for (int u = 0; u < KM_SUB; u++) {
+        const km_v4i* buf = s_a[tile & 1][u];
+        km_v16i acc[KM_QT];
 #pragma unroll
-        for (int t = 0; t < KM_QT; t++)
-          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[t][s], s == 0 ? zero : acc[t], 0, 0, 0);
-      }
-      // acc[t][j] = dot(query of this lane in tile t, database row tile * 32 + (j & 3) + 8 * (j >> 2) + 4 h)
-      const int row0 = tile * 32 + 4 * h;
+        for (int s = 0; s < 8; s++) {
+          const km_v4i a = buf[(2 * s + h) * 32 + r];
 #pragma unroll
-      for (int t = 0; t < KM_QT; t++) {
-        int m = acc[t][0];
+          for (int t = 0; t < KM_QT; t++)
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[t][s], s == 0 ? zero : acc[t], 0, 0, 0);
+        }
+        // acc[t][j] = dot(query of this lane in tile t, database row row0 + (j & 3) + 8 * (j >> 2))
+        const int row0 = (tile * KM_SUB + u) * 32 + 4 * h;
 #pragma unroll
-        for (int j = 1; j < 16; j++) m = max(m, acc[t][j]);
-        if (__builtin_amdgcn_ballot_w64(m > thr[t]) != 0) {
-          int rbase = row0;
-          asm volatile("" : "+v"(rbase));  // keeps the 16 row indices out of the registers of the common path
+        for (int t = 0; t < KM_QT; t++) {
+          int m = acc[t][0];
 #pragma unroll
-          for (int j = 0; j < 16; j++) {
-            const int row = rbase + (j & 3) + 8 * (j >> 2);
-            const uint32_t key = row < cn ? ((uint32_t)(256 - acc[t][j]) << KM_ROWBITS) | (uint32_t)row : 0xFFFFFFFFu;
-            // two smallest keys: k1 <= k2 always, so the new second is the median of the three
-            const uint32_t lo = min(k1[t], key);
-            k2[t] = max(min(k2[t], key), min(max(k1[t], key), k2[t]));
-            k1[t] = lo;
+          for (int j = 1; j < 16; j++) m = max(m, acc[t][j]);
+          if (__builtin_amdgcn_ballot_w64(m > thr[t]) != 0) {
+            int rbase = row0;
+            asm volatile("" : "+v"(rbase));  // keeps the 16 row indices out of the registers of the common path
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+              const int row = rbase + (j & 3) + 8 * (j >> 2);
+              const uint32_t key = row < cn ? ((uint32_t)(256 - acc[t][j]) << KM_ROWBITS) | (uint32_t)row : 0xFFFFFFFFu;
+              // two smallest keys: k1 <= k2 always, so the new second is the median of the three
+              const uint32_t lo = min(k1[t], key);
+              k2[t] = max(min(k2[t], key), min(max(k1[t], key), k2[t]));
+              k1[t] = lo;
+            }
+            thr[t] = k2[t] == 0xFFFFFFFFu ? -100000 : 256 - (int)(k2[t] >> KM_ROWBITS);
           }
-          thr[t] = k2[t] == 0xFFFFFFFFu ? -100000 : 256 - (int)(k2[t] >> KM_ROWBITS);
         }
       }
     }
