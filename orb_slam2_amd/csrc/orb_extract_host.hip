@@ -4,7 +4,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "orb_common.h"
@@ -47,6 +50,73 @@ static inline int cv_round(double v) { return (int)lrint(v); }
 }  // namespace orbhip
 
 using namespace orbhip;
+
+// A few host threads that share the packing of a batch into / out of the pinned staging
+// buffers: one thread copies at about 10 GB/s, far less than the DMA engines and the kernels
+// take.  parallel_for(n, f) runs f(0) .. f(n - 1) on the workers and the caller, and returns
+// when all are done.
+class HostCopyPool {
+ public:
+  explicit HostCopyPool(int workers) {
+    for (int i = 0; i < workers; i++) threads_.emplace_back([this] { run(); });
+  }
+  ~HostCopyPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  void parallel_for(int n, const std::function<void(int)>& f) {
+    if (n <= 0) return;
+    uint64_t gen;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      job_ = &f; count_ = n; next_ = 0; left_ = n; gen = ++gen_;
+    }
+    cv_.notify_all();
+    work(gen);
+    std::unique_lock<std::mutex> l(m_);
+    done_.wait(l, [this] { return left_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  // items are handed out under the lock and only to threads working on generation `gen`, so a
+  // worker that wakes up late can never take an item of a later call
+  void work(uint64_t gen) {
+    for (;;) {
+      const std::function<void(int)>* f;
+      int i;
+      {
+        std::lock_guard<std::mutex> l(m_);
+        if (gen_ != gen || job_ == nullptr || next_ >= count_) return;
+        i = next_++;
+        f = job_;
+      }
+      (*f)(i);
+      std::lock_guard<std::mutex> l(m_);
+      if (--left_ == 0) done_.notify_all();
+    }
+  }
+  void run() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return stop_ || (gen_ != seen && job_ != nullptr); });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work(seen);
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* job_ = nullptr;
+  int count_ = 0, next_ = 0, left_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
 
 struct OrbExtractor {
   int nfeatures, nlevels, iniTh, minTh, device;
@@ -91,6 +161,7 @@ struct OrbExtractor {
   int* d_nout = nullptr;
   size_t out_cap = 0;  // frames*max_kp the output staging holds
   int out_frames = 0;
+  HostCopyPool* pool = nullptr;  // created by the first call that packs more than a few MB
   // stage timing
   bool profiling = false;
   int channels = 1;       // interleaved bytes per input pixel: 1 grey, 3, 4
@@ -100,6 +171,9 @@ struct OrbExtractor {
 };
 
 namespace {
+
+constexpr int kPoolThreads = 8;                    // host threads that pack a large batch (the caller is one)
+constexpr size_t kPoolMinBytes = (size_t)4 << 20;  // smaller batches are packed by the caller alone
 
 void free_plan_buffers(OrbExtractor* h) {
   hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_xtab); hipFree(h->d_ytab);
@@ -444,6 +518,7 @@ void orb_extractor_destroy(OrbExtractor* h) {
   hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_nout);
   if (h->h_img) hipHostFree(h->h_img);
   if (h->h_out) hipHostFree(h->h_out);
+  delete h->pool;
   for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
   delete h;
@@ -576,13 +651,28 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
     ORB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_img), img_bytes, hipHostMallocDefault));
     h->h_img_bytes = img_bytes;
   }
-  for (int k = 0; k < n_frames; k++) {
+  const size_t frame_bytes = (size_t)rows * row_bytes;
+  auto pack = [&](int k) {
     const uint8_t* src = images + (size_t)k * frame_stride;
-    uint8_t* dst = h->h_img + (size_t)k * rows * row_bytes;
-    if (stride == row_bytes) memcpy(dst, src, (size_t)rows * row_bytes);
+    uint8_t* dst = h->h_img + (size_t)k * frame_bytes;
+    if (stride == row_bytes) memcpy(dst, src, frame_bytes);
     else for (int r = 0; r < rows; r++) memcpy(dst + (size_t)r * row_bytes, src + (size_t)r * stride, row_bytes);
+  };
+  if (n_frames < 4 || img_bytes < kPoolMinBytes) {
+    for (int k = 0; k < n_frames; k++) pack(k);
+    ORB_HIP_CHECK(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, st));
+  } else {
+    // large batches: the packing is shared by a few threads, and the DMA of one chunk of frames
+    // runs while the next chunk is packed
+    if (!h->pool) h->pool = new HostCopyPool(kPoolThreads - 1);
+    const int chunk = std::max(kPoolThreads, (int)((size_t)(8u << 20) / frame_bytes));
+    for (int k0 = 0; k0 < n_frames; k0 += chunk) {
+      const int kn = std::min(chunk, n_frames - k0);
+      h->pool->parallel_for(kn, [&](int i) { pack(k0 + i); });
+      ORB_HIP_CHECK(hipMemcpyAsync(h->d_img + (size_t)k0 * frame_bytes, h->h_img + (size_t)k0 * frame_bytes,
+                                   (size_t)kn * frame_bytes, hipMemcpyHostToDevice, st));
+    }
   }
-  ORB_HIP_CHECK(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, st));
   rc = enqueue(h, n_frames, h->d_img, row_bytes, (size_t)rows * row_bytes, max_kp, h->d_kps, h->d_desc, h->d_nout, st);
   if (rc != ORBHIP_OK) return rc;
   // results come back through pinned staging as well: two DMAs for the batch, then the valid
@@ -605,13 +695,17 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   int status = ORBHIP_OK;
   for (int k = 0; k < n_frames; k++) {
     n_out[k] = s_n[k];
-    const int n = std::min(n_out[k], max_kp);
     if (n_out[k] > max_kp) { set_error("max_kp too small: a frame produced " + std::to_string(n_out[k]) + " keypoints"); status = ORBHIP_ERR_CAPACITY; }
+  }
+  auto unpack = [&](int k) {
+    const int n = std::min(s_n[k], max_kp);
     if (n > 0) {
       memcpy(keypoints + (size_t)k * max_kp, s_kps + (size_t)k * max_kp, sizeof(OrbKeyPoint) * n);
       memcpy(descriptors + (size_t)k * max_kp * 32, s_desc + (size_t)k * max_kp * 32, 32 * (size_t)n);
     }
-  }
+  };
+  if (h->pool && n_frames >= 4) h->pool->parallel_for(n_frames, unpack);
+  else for (int k = 0; k < n_frames; k++) unpack(k);
   return status;
 }
 
