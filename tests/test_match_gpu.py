@@ -688,7 +688,8 @@ def test_search_for_initialization(oracle, seed, n, win, ratio, ori):
 
 
 @pytest.mark.parametrize("nq,ndb,seed", [(1, 1, 0), (37, 5, 1), (512, 2048, 2), (513, 2079, 3), (1000, 33, 4),
-                                          (3000, 10000, 5), (64, 70001, 6)])
+                                          (3000, 10000, 5), (64, 70001, 6),
+                                          (300, (1 << 21) + 70000, 7)])  # the last: more rows than one key chunk holds
 def test_knn2_matrix_core_kernel_equals_popcount_kernel(oracle, nq, ndb, seed):
     """The two kNN-2 kernels (vector popcount / int8 matrix cores) return the same integers,
     ties included, and both equal the oracle."""
@@ -704,6 +705,8 @@ def test_knn2_matrix_core_kernel_equals_popcount_kernel(oracle, nq, ndb, seed):
     flips = rng.integers(0, 2, nq).astype(bool)
     q[flips] = flip_bits(rng, q[flips], 40) if flips.any() else q[flips]
     q[::7] = rng.integers(0, 256, (len(q[::7]), 32), dtype=np.uint8)
+    if nq >= 8 and ndb > 8:
+        q[1:5] = db[[0, 1, ndb // 2, ndb - 1]]  # the duplicated rows themselves: distance 0 twice
     d_q, d_db = torch.from_numpy(q).cuda(), torch.from_numpy(db).cuda()
     outs = []
     for algo in (1, 2):
