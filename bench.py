@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--knn", type=int, default=1000000, help="queries = database rows of the kNN-2 leg (0 = skip)")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1: the matcher of step k runs on a second stream beside the extraction of step k+1 "
+                         "(two sets of keypoint buffers); 0: one stream")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -89,14 +92,19 @@ def main():
     d_img = torch.from_numpy(seq).to(dev)
     ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)
     max_kp = ex.max_keypoints(ROWS, COLS)
-    d_kps = torch.zeros((B, max_kp, 6), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((B, max_kp, 32), dtype=torch.uint8, device=dev)
-    d_nout = torch.zeros(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # two sets of extractor outputs: with --overlap the matcher reads one while the next step fills the other
+    nsets = 2 if args.overlap else 1
+    kps_sets = [torch.zeros((B, max_kp, 6), dtype=torch.float32, device=dev) for _ in range(nsets)]
+    desc_sets = [torch.zeros((B, max_kp, 32), dtype=torch.uint8, device=dev) for _ in range(nsets)]
+    nout_sets = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nsets)]
+    d_kps, d_desc, d_nout = kps_sets[0], desc_sets[0], nout_sets[0]
+    s_ex = torch.cuda.current_stream()
+    s_m = torch.cuda.Stream(device=dev) if args.overlap else s_ex
+    stream = s_ex.cuda_stream
 
-    def extract():
-        ex.extract_batch_device(d_img.data_ptr(), B, ROWS, COLS, d_kps.data_ptr(), d_desc.data_ptr(),
-                                d_nout.data_ptr(), max_kp, stream=stream)
+    def extract(s=0):
+        ex.extract_batch_device(d_img.data_ptr(), B, ROWS, COLS, kps_sets[s].data_ptr(), desc_sets[s].data_ptr(),
+                                nout_sets[s].data_ptr(), max_kp, stream=s_ex.cuda_stream)
 
     extract()
     torch.cuda.synchronize()
@@ -122,20 +130,38 @@ def main():
     bounds = FrameBounds(0.0, float(COLS), 0.0, float(ROWS))
     kp_bytes = max_kp * 24
 
-    def match():
+    def match(s=0):
+        n, k, d = nout_sets[s].data_ptr(), kps_sets[s].data_ptr(), desc_sets[s].data_ptr()
         check(L.orb_search_by_projection_frames_device(
             local, npairs, max_kp, max_kp, d_tcw.data_ptr(), fx, fy, cx, cy, bounds, sf.ctypes.data, NLEVELS,
-            d_nout.data_ptr(), d_kps.data_ptr(), d_last_obs.data_ptr(), d_xw.data_ptr(), d_desc.data_ptr(),
-            d_nout.data_ptr() + 4, d_kps.data_ptr() + kp_bytes, d_desc.data_ptr() + max_kp * 32, d_cur_obs.data_ptr(),
-            7.0, 1, d_scratch.data_ptr(), scratch_bytes, d_match.data_ptr(), d_nm.data_ptr(), stream))
+            n, k, d_last_obs.data_ptr(), d_xw.data_ptr(), d,
+            n + 4, k + kp_bytes, d + max_kp * 32, d_cur_obs.data_ptr(),
+            7.0, 1, d_scratch.data_ptr(), scratch_bytes, d_match.data_ptr(), d_nm.data_ptr(), s_m.cuda_stream))
 
-    def step():
-        extract()
-        match()
+    ex_done = [torch.cuda.Event() for _ in range(nsets)]
+    m_done = [torch.cuda.Event() for _ in range(nsets)]
+
+    def step(k, ev_a=None, ev_b=None):
+        """Extraction of step k on s_ex, its matching on s_m; set k % nsets is refilled only after the
+        matcher of step k - nsets has read it.  With one stream the waits are no-ops."""
+        s = k % nsets
+        if args.overlap and k >= nsets:
+            s_ex.wait_event(m_done[s])
+        extract(s)
+        if args.overlap:
+            ex_done[s].record(s_ex)
+            s_m.wait_event(ex_done[s])
+        if ev_a is not None:
+            ev_a.record(s_m)
+        match(s)
+        if ev_b is not None:
+            ev_b.record(s_m)
+        if args.overlap:
+            m_done[s].record(s_m)
 
     # ---------------- timed region ----------------
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     barrier()
     L.orb_extractor_set_profiling(ex._h, 1)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -144,10 +170,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for k in range(args.steps):
-        extract()
-        ev_m0[k].record()
-        match()
-        ev_m1[k].record()
+        step(k, ev_m0[k], ev_m1[k])
     ev1.record()
     barrier()
     t1 = time.perf_counter()
@@ -273,7 +296,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "KITTI-shaped 1241x376 sequence, 2000 features, 8 levels, scale 1.2, FAST 20/7; "
                                    "extract + frame-to-frame SearchByProjection(th=7)",
-                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": npairs,
+                       "frames_per_gpu_per_step": B, "streams": 2 if args.overlap else 1, "pairs_per_gpu_per_step": npairs,
                        "keypoints_per_frame": round(nkp / B, 1), "matches_per_pair": round(nmatch / npairs, 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(gbs[dom], 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(gbs[dom] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom),

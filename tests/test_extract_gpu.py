@@ -219,6 +219,27 @@ def test_full_size_properties_batch():
     assert ((counts >= q) & (counts <= q + 3)).all()
 
 
+def test_large_batch_equals_small_batches(oracle):
+    """Batches over 128 frames take another dispatch order in the blur and the threaded packing
+    of the host path: 139 distinct frames (not a multiple of 8) in one call equal the same
+    frames in calls of 5, and a few of them are checked against the oracle."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd.synth import synth_sequence
+    n = 139
+    seq = synth_sequence(168, 224, n, seed=17, step=1)
+    ex = ORBextractor(300, 1.2, 6, 20, 7)
+    bk, bd = ex.extract_batch(seq)
+    ex2 = ORBextractor(300, 1.2, 6, 20, 7)
+    for f0 in range(0, n, 5):
+        sk, sd = ex2.extract_batch(seq[f0:f0 + 5])
+        for i in range(len(sk)):
+            assert np.array_equal(bk[f0 + i], sk[i]) and np.array_equal(bd[f0 + i], sd[i]), f0 + i
+    ref = oracle.Extractor(300, 1.2, 6, 20, 7)
+    for f in (0, 127, 128, 136, 138):
+        rk, rd = ref(seq[f])
+        check_against(bk[f], bd[f], rk, rd)
+
+
 def _colour_image(rows, cols, ch, seed):
     """A colour image whose grey value has corners: the synthetic grey scene modulated per
     channel, plus noise, so that the three weights all matter."""
