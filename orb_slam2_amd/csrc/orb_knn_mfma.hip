@@ -11,8 +11,9 @@
 // once into registers (KM_QT * 8 K-steps * 16 bytes per lane).  Database rows stream through
 // LDS 32 at a time: the workgroup expands the packed 32 x 32 bytes to 32 x 256 int8 (through a
 // byte -> 8 bytes table in LDS; double buffered, one barrier per tile) in the fragment order of
-// the A operand, every wavefront
-// reads the eight A fragments (one ds_read_b128 each) and issues 8 * KM_QT MFMAs.  In the
+// the A operand, every wavefront reads the eight A fragments (one ds_read_b128 each; the first
+// three are requested before the next tile is expanded, so that the MFMAs can start right after
+// the barrier) and issues 8 * KM_QT MFMAs.  In the
 // 32x32 result a lane holds one query (column) and 16 database rows; it keeps the two
 // smallest (distance, row) keys of its rows, lanes l and l + 32 (same query, other rows) are
 // merged at the end.  Rows arrive in ascending order, so after the first few thousand a tile
@@ -30,7 +31,7 @@ constexpr int KM_THREADS = 256;        // 4 wavefronts
 constexpr int KM_QT = 4;               // query tiles (of 32) per wavefront
 constexpr int KM_QPW = 32 * KM_QT;     // queries per wavefront
 constexpr int KM_QPB = KM_QPW * (KM_THREADS / 64);
-constexpr int KM_SUB = 1;               // 32-row tiles expanded per barrier (2 measured the same)
+constexpr int KM_EARLY = 3;            // A fragments requested before the expansion of the next tile
 constexpr int KM_ROWBITS = 21;         // key = (256 - dot) << 21 | row; 256 - dot = 2 * distance <= 512
 constexpr int KM_CHUNK = 1 << KM_ROWBITS;
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
                                                               int* __restrict__ out_second, int* __restrict__ out_idx,
                                                               uint8_t* __restrict__ out_accept) {
   // A fragments of one 32-row tile: [group g = 2 * kstep + half][row][16 bytes], two buffers
-  __shared__ __attribute__((aligned(16))) km_v4i s_a[2][KM_SUB][16 * 32];
+  __shared__ __attribute__((aligned(16))) km_v4i s_a[2][16 * 32];
   // 8 descriptor bits -> 8 bytes of +1 / -1; entry 256 (all zero) stands for rows past the end
   __shared__ __attribute__((aligned(8))) uint2 s_lut[257];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -89,47 +90,57 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
 
   for (int cbase = 0; cbase < ndb; cbase += KM_CHUNK) {
     const int cn = min(KM_CHUNK, ndb - cbase);
-    const int ntiles = (cn + 32 * KM_SUB - 1) / (32 * KM_SUB);  // tiles of 32 * KM_SUB rows
+    const int ntiles = (cn + 31) >> 5;
     uint32_t k1[KM_QT], k2[KM_QT];
     int thr[KM_QT];  // an accumulator must exceed this to change (k1, k2)
 #pragma unroll
     for (int t = 0; t < KM_QT; t++) { k1[t] = 0xFFFFFFFFu; k2[t] = 0xFFFFFFFFu; thr[t] = -100000; }
-    uint32_t pk[KM_SUB][2];
+    uint32_t pk0 = 0, pk1 = 0;
     auto fetch = [&](int tile) {
-#pragma unroll
-      for (int u = 0; u < KM_SUB; u++) {
-        const int row = (tile * KM_SUB + u) * 32 + er;
-        const size_t o = (size_t)(cbase + (row < cn ? row : 0)) * 16;
-        pk[u][0] = db16[o + eg0];
-        pk[u][1] = db16[o + eg0 + 8];
-      }
+      const int row = tile * 32 + er;
+      const size_t o = (size_t)(cbase + (row < cn ? row : 0)) * 16;
+      pk0 = db16[o + eg0];
+      pk1 = db16[o + eg0 + 8];
     };
+    // the packed rows in (pk0, pk1) go to buffer `tile & 1` as A fragments
+    auto expand = [&](int tile) {
+      const bool v = tile * 32 + er < cn;
+      km_v4i* buf = s_a[tile & 1];
+      const uint2 a0 = s_lut[v ? (pk0 & 255u) : 256u], a1 = s_lut[v ? (pk0 >> 8) : 256u];
+      const uint2 c0 = s_lut[v ? (pk1 & 255u) : 256u], c1 = s_lut[v ? (pk1 >> 8) : 256u];
+      buf[eg0 * 32 + er] = km_v4i{(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
+      buf[(eg0 + 8) * 32 + er] = km_v4i{(int)c0.x, (int)c0.y, (int)c1.x, (int)c1.y};
+    };
+    // In iteration i the fragments of tile i (complete since the barrier of iteration i - 1)
+    // are requested first and tile i + 1 is expanded into the other buffer while they travel.
+    // A barrier waits for the LDS reads issued before it, so after the barrier of iteration
+    // i - 1 every wavefront holds tile i - 1 in registers and its buffer may be overwritten.
     fetch(0);
+    expand(0);
+    if (ntiles > 1) fetch(1);
+    __syncthreads();
     for (int tile = 0; tile < ntiles; tile++) {
+      const km_v4i* buf = s_a[tile & 1];
+      km_v4i a[8];  // the first KM_EARLY fragments before the barrier, the others behind the first MFMAs
 #pragma unroll
-      for (int u = 0; u < KM_SUB; u++) {
-        const bool v = (tile * KM_SUB + u) * 32 + er < cn;
-        km_v4i* buf = s_a[tile & 1][u];
-        const uint2 a0 = s_lut[v ? (pk[u][0] & 255u) : 256u], a1 = s_lut[v ? (pk[u][0] >> 8) : 256u];
-        const uint2 c0 = s_lut[v ? (pk[u][1] & 255u) : 256u], c1 = s_lut[v ? (pk[u][1] >> 8) : 256u];
-        buf[eg0 * 32 + er] = km_v4i{(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
-        buf[(eg0 + 8) * 32 + er] = km_v4i{(int)c0.x, (int)c0.y, (int)c1.x, (int)c1.y};
+      for (int s = 0; s < KM_EARLY; s++) a[s] = buf[(2 * s + h) * 32 + r];
+      if (tile + 1 < ntiles) {
+        expand(tile + 1);
+        if (tile + 2 < ntiles) fetch(tile + 2);  // in flight during the MFMAs
       }
       __syncthreads();
-      if (tile + 1 < ntiles) fetch(tile + 1);  // in flight during the MFMAs
+      {
 #pragma unroll
-      for (int u = 0; u < KM_SUB; u++) {
-        const km_v4i* buf = s_a[tile & 1][u];
+        for (int s = KM_EARLY; s < 8; s++) a[s] = buf[(2 * s + h) * 32 + r];
         km_v16i acc[KM_QT];
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-          const km_v4i a = buf[(2 * s + h) * 32 + r];
 #pragma unroll
           for (int t = 0; t < KM_QT; t++)
-            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[t][s], s == 0 ? zero : acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[t][s], s == 0 ? zero : acc[t], 0, 0, 0);
         }
         // acc[t][j] = dot(query of this lane in tile t, database row row0 + (j & 3) + 8 * (j >> 2))
-        const int row0 = (tile * KM_SUB + u) * 32 + 4 * h;
+        const int row0 = tile * 32 + 4 * h;
 #pragma unroll
         for (int t = 0; t < KM_QT; t++) {
           int m = acc[t][0];
