@@ -721,3 +721,65 @@ def test_knn2_matrix_core_kernel_equals_popcount_kernel(oracle, nq, ndb, seed):
     wb, ws, wi, wa = oracle.knn2_bruteforce(q, db, 0.7)
     assert np.array_equal(outs[1][0][0], wb) and np.array_equal(outs[1][0][1], ws)
     assert np.array_equal(outs[1][0][2], wi + 1000) and np.array_equal(outs[1][1], wa)
+
+
+def test_knn2_full_size_properties(oracle):
+    """The 1M x 1M kNN-2 of the benchmark, checked through properties that need no full CPU scan:
+    planted queries find their source row at the planted distance; a sample of queries equals
+    the oracle; the popcount kernel agrees on a sample; eight ascending shards merged equal the
+    single scan bit for bit (the multi-GPU decomposition, run here on one GPU)."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from orb_slam2_amd import _lib
+    from orb_slam2_amd.synth import synth_descriptors
+    L = _lib.lib()
+    n = 1000000
+    db, q = synth_descriptors(n, n, seed=1)
+    # the generator's planted half: source rows and the distance that is left after the flips
+    rq = np.random.default_rng(2)
+    rq.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    src = rq.integers(0, n, size=n // 2)
+    planted_d = np.unpackbits(q[:n // 2] ^ db[src], axis=1).sum(1).astype(np.int32)
+    assert planted_d.max() <= 40
+    d_q, d_db = torch.from_numpy(q).cuda(), torch.from_numpy(db).cuda()
+
+    def scan(qptr, nq, lo, hi, algo=0):
+        res = torch.full((3, nq), -7, dtype=torch.int32, device="cuda")
+        acc = torch.zeros(nq, dtype=torch.uint8, device="cuda")
+        _lib.check(L.orb_knn2_device_algo(0, C.c_void_p(qptr), nq, C.c_void_p(d_db.data_ptr() + 32 * lo), hi - lo, lo, 0.7,
+                                          C.c_void_p(res[0].data_ptr()), C.c_void_p(res[1].data_ptr()),
+                                          C.c_void_p(res[2].data_ptr()), C.c_void_p(acc.data_ptr()), None, algo))
+        return res, acc
+
+    full, facc = scan(d_q.data_ptr(), n, 0, n)
+    torch.cuda.synchronize()
+    best, second, idx = (x.cpu().numpy() for x in full)
+    acc = facc.cpu().numpy()
+    # planted queries: nothing among a million random rows comes near 40 bits
+    assert np.array_equal(best[:n // 2], planted_d) and np.array_equal(idx[:n // 2], src)
+    assert (second >= best).all() and (idx >= 0).all() and (idx < n).all()
+    assert np.array_equal(acc, (best.astype(np.float32) < np.float32(0.7) * second.astype(np.float32)).astype(np.uint8))
+    # the distance reported is the distance to the row reported
+    sample = np.random.default_rng(5).integers(0, n, 4096)
+    assert np.array_equal(np.unpackbits(q[sample] ^ db[idx[sample]], axis=1).sum(1), best[sample])
+    # oracle on 48 queries of each half
+    pick = np.concatenate([np.arange(48), n // 2 + np.arange(48)])
+    wb, ws, wi, wa = oracle.knn2_bruteforce(q[pick], db, 0.7)
+    assert np.array_equal(best[pick], wb) and np.array_equal(second[pick], ws) and np.array_equal(idx[pick], wi)
+    assert np.array_equal(acc[pick], wa)
+    # the popcount kernel on 4096 consecutive queries across the middle
+    lo_q = n // 2 - 2048
+    pres, pacc = scan(d_q.data_ptr() + 32 * lo_q, 4096, 0, n, algo=1)
+    torch.cuda.synchronize()
+    assert torch.equal(pres, full[:, lo_q:lo_q + 4096]) and torch.equal(pacc, facc[lo_q:lo_q + 4096])
+    # eight shards, merged
+    shards = [scan(d_q.data_ptr(), n, n * r // 8, n * (r + 1) // 8)[0] for r in range(8)]
+    g = torch.stack(shards, 1).contiguous()  # [3][8][n]
+    out = torch.zeros((3, n), dtype=torch.int32, device="cuda")
+    macc = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    _lib.check(L.orb_knn2_merge_device(0, 8, n, C.c_void_p(g[0].data_ptr()), C.c_void_p(g[1].data_ptr()),
+                                       C.c_void_p(g[2].data_ptr()), 0.7, C.c_void_p(out[0].data_ptr()),
+                                       C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()),
+                                       C.c_void_p(macc.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, full) and torch.equal(macc, facc)
