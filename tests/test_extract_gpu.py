@@ -79,6 +79,37 @@ def test_extract_4k_frame(oracle):
         assert np.array_equal(ex.fast_candidates(l), ref.candidates(l))
 
 
+def test_extract_4k_batch_properties():
+    """One rank's share of the 64-frame 3840x2160 batch (8 frames, device resident): every frame
+    of the batch equals the same image extracted alone (which the test above checks against the
+    oracle), whatever its place in the batch."""
+    torch = pytest.importorskip("torch")
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd._lib import KP_DTYPE
+    from orb_slam2_amd.synth import synth_image
+    rows, cols, n = 2160, 3840, 8
+    base = [synth_image(rows, cols, 7, n_shapes=20000), synth_image(rows, cols, 8, n_shapes=12000)]
+    order = [0, 1, 1, 0, 0, 0, 1, 0]
+    ex = ORBextractor(4000, 1.2, 8, 20, 7)
+    singles = [ex(im) for im in base]
+    batch = np.stack([base[o] for o in order])
+    cap = ex.max_keypoints(rows, cols)
+    d = torch.from_numpy(batch).cuda()
+    kps = torch.zeros((n, cap, 6), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d.data_ptr(), n, rows, cols, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(), cap,
+                            stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    hk, hd, hn = kps.cpu().numpy(), desc.cpu().numpy(), nout.cpu().numpy()
+    for f in range(n):
+        sk, sd = singles[order[f]]
+        assert hn[f] == len(sk) >= 4000
+        got = np.ascontiguousarray(hk[f, :hn[f]]).view(KP_DTYPE).reshape(-1)
+        assert np.array_equal(got, sk), f
+        assert np.array_equal(hd[f, :hn[f]], sd), f
+
+
 @pytest.mark.parametrize("name", ["small_240x320", "tum_480x640", "kitti_376x1241", "euroc_480x752"])
 def test_extract_matches_golden(name):
     from orb_slam2_amd import ORBextractor
