@@ -352,7 +352,9 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
 
   const FastItem item = items[blockIdx.y];
   const int f = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the wave index as a scalar: loops over "rows of this wave" are then uniform for the compiler,
+  // and the queue length and list addresses stay in scalar registers
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const LevelGeom& L = P.lv[item.level];
   const int wCell = L.wCell, hCell = L.hCell;
   const int iniY = kBorder + item.row * hCell;
@@ -395,7 +397,10 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   if (tid < F_MAXCELLS) s_cnt[tid] = 0;
   __syncthreads();
 
-  const unsigned long long lt_mask = (1ull << lane) - 1;
+  // number of set bits of a wave mask below this lane (v_mbcnt_lo / v_mbcnt_hi)
+  auto below = [](unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  };
   unsigned cellmask = (1u << item.ncells) - 1;  // cells to (re)compute in this pass
   int ncorner = 0;                              // wave-uniform: entries in this wave's corner list
   bool overflow = false;                        // wave-uniform: corner list too small, sweep densely
@@ -417,10 +422,10 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       }
       // a pixel that either polarity could make a corner (rare) goes to the queue's tail once
       // more, marked (bit 15) for the darker ring
-      const unsigned long long ma = __ballot(again);
+      const unsigned long long ma = __builtin_amdgcn_ballot_w64(again);
       if (ma) {
         if (qn + __popcll(ma) <= F_QCAP) {
-          if (again) s_list[wave][qn + __popcll(ma & lt_mask)] = (uint16_t)(e | 0x8000);
+          if (again) s_list[wave][qn + below(ma)] = (uint16_t)(e | 0x8000);
           qn += __popcll(ma);
         } else if (again) {  // no room left in the queue: the second polarity right here
           bool unused;
@@ -430,10 +435,10 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         }
       }
       e &= 0x7FFF;
-      const unsigned long long m = __ballot(corner);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);
       const int nc = __popcll(m);
       if (ncorner + nc > F_CCAP) overflow = true;
-      else if (corner) s_corner[wave][ncorner + __popcll(m & lt_mask)] = (uint16_t)e;
+      else if (corner) s_corner[wave][ncorner + below(m)] = (uint16_t)e;
       if (!overflow) ncorner += nc;
     };
 
@@ -456,14 +461,17 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       const int li = lane & ((1 << lsh) - 1), sub = lane >> lsh;
       const int col4 = lc0 + 4 * li;
       bool mine[4];
+      unsigned long long mine_mask[4];  // the same as wave masks
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int x = col4 + j - xoff;
         mine[j] = li < nl && x >= x0 && x < x1;
+        mine_mask[j] = __builtin_amdgcn_ballot_w64(mine[j]);
       }
       for (int yb = wave * rps; yb < hi; yb += (F_THREADS / 64) * rps) {
         const int y = min(yb + sub, hi - 1);
         const bool vy = yb + sub < hi;
+        const unsigned long long row_mask = __builtin_amdgcn_ballot_w64(vy);
         const uint8_t* rowp = &s_img[(y + 3) * F_PITCH + col4];
         const uint32_t C = *reinterpret_cast<const uint32_t*>(rowp);
         const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4);
@@ -482,11 +490,14 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
           const int hi = c + t, lo = c - t;
           const int p0 = (int)((D >> (8 * j)) & 0xFFu), p8 = (int)((U >> (8 * j)) & 0xFFu);
           const int p4 = (int)((E >> (8 * j)) & 0xFFu), p12 = (int)((W >> (8 * j)) & 0xFFu);
-          const bool br = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));
-          const bool dk = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo));
+          const bool br = min(max(p0, p8), max(p4, p12)) > hi;
+          const bool dk = max(min(p0, p8), min(p4, p12)) < lo;
           const bool ok = vy & mine[j] & (br | dk);
-          const unsigned long long m = __ballot(ok);
-          if (ok) s_list[wave][qn + __popcll(m & lt_mask)] = (uint16_t)((y << 8) | (col4 + j));
+          // the mask of `ok` from the masks of the two comparisons (a ballot of the combined
+          // predicate would be rebuilt from a select and a compare)
+          const unsigned long long m =
+              (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & mine_mask[j] & row_mask;
+          if (ok) s_list[wave][qn + below(m)] = (uint16_t)((y << 8) | (col4 + j));
           qn += __popcll(m);
         }
         if (qn >= 64) {
@@ -556,8 +567,8 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         const int k = k0 + lane;
         const int e = k < ncorner ? (int)s_corner[wave][k] : 0;
         const bool keep = k < ncorner && !((need >> (((e & 0xFF) - xoff) / wCell)) & 1u);
-        const unsigned long long m = __ballot(keep);
-        if (keep) s_corner[wave][kept + __popcll(m & lt_mask)] = (uint16_t)e;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) s_corner[wave][kept + below(m)] = (uint16_t)e;
         kept += __popcll(m);
       }
       ncorner = kept;
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     int nk = 0;
     for (int k0 = 0; k0 < ncorner; k0 += 64) {
       const int k = k0 + lane;
-      nk += __popcll(__ballot(k < ncorner && (s_corner[wave][k] & 0x8000)));
+      nk += __popcll(__builtin_amdgcn_ballot_w64(k < ncorner && (s_corner[wave][k] & 0x8000)));
     }
     if (nk == 0) return;  // wave-uniform
     int wbase = 0;
@@ -586,11 +597,11 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       const int k = k0 + lane;
       const int e = k < ncorner ? (int)s_corner[wave][k] : 0;
       const bool kept = (e & 0x8000) != 0;
-      const unsigned long long m = __ballot(kept);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(kept);
       if (kept) {
         const int ex = (e & 0xFF) - xoff, ey = (e >> 8) & 0x7F;
         const int v = s_v[(ey + 3) * F_PITCH + (e & 0xFF)];
-        const int slot = wbase + __popcll(m & lt_mask);
+        const int slot = wbase + below(m);
         const int xr = xb + 3 + ex - kBorder, yr = iniY + 3 + ey - kBorder;
         if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
       }
@@ -771,7 +782,7 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
         int s = 0;
         bool fl = false;
         if (idx >= 0) { s = S.bykey[idx]; fl = S.count[s] > 1; }
-        const unsigned long long m = __ballot(fl);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(fl);
         if (lane == 0) S.wsum[wave] = __popcll(m);
         __syncthreads();
         int woff = 0, all = 0;
@@ -844,7 +855,7 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
         g += cg; c += cc;
         if (i < E) { S.cumg[i] = (short)g; S.cumc[i] = (short)c; }
         if (mode == 1 && pn_ < 0) {
-          const unsigned long long hit = __ballot(i < E && size + g >= N);
+          const unsigned long long hit = __builtin_amdgcn_ballot_w64(i < E && size + g >= N);
           if (hit) pn_ = base + __ffsll((long long)hit);  // index of first hit + 1
         }
         cg = __shfl(g, 63); cc = __shfl(c, 63);
@@ -1278,7 +1289,7 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   }
   unsigned long long bits[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) bits[j] = __ballot(t0[j] < t1[j]);
+  for (int j = 0; j < 4; j++) bits[j] = __builtin_amdgcn_ballot_w64(t0[j] < t1[j]);
   if (lane < 4) {
     const unsigned long long w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
     reinterpret_cast<unsigned long long*>(out_desc + ((size_t)f * max_kp + o) * 32)[lane] = w;
