@@ -60,6 +60,9 @@ def main():
                     help="1: the matcher of step k runs on a second stream beside the extraction of step k+1 "
                          "(two sets of keypoint buffers); 0: one stream")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--knn-reps", type=int, default=3, help="timed repetitions of the kNN-2 leg (the median is reported)")
+    ap.add_argument("--knn-popcount", type=int, default=1, help="1: also time the popcount kernel once on the same input")
+    ap.add_argument("--host-reps", type=int, default=5, help="repetitions of the host-buffer batch call (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -81,62 +84,31 @@ def main():
         torch.cuda.synchronize()
 
     from orb_slam2_amd import _lib
-    from orb_slam2_amd._lib import FrameBounds, check
-    from orb_slam2_amd.extractor import ORBextractor
+    from orb_slam2_amd import dist as odist
+    from orb_slam2_amd._lib import KP_DTYPE, check
+    from orb_slam2_amd.chain import DeviceChain
     from orb_slam2_amd.synth import synth_descriptors, synth_sequence
     L = _lib.lib()
 
     B = args.batch
     # ---------------- inputs (not timed) ----------------
     seq = synth_sequence(ROWS, COLS, B, seed=1000 + rank, step=2)
-    d_img = torch.from_numpy(seq).to(dev)
-    ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local)
-    max_kp = ex.max_keypoints(ROWS, COLS)
     # two sets of extractor outputs: with --overlap the matcher reads one while the next step fills the other
     nsets = 2 if args.overlap else 1
-    kps_sets = [torch.zeros((B, max_kp, 6), dtype=torch.float32, device=dev) for _ in range(nsets)]
-    desc_sets = [torch.zeros((B, max_kp, 32), dtype=torch.uint8, device=dev) for _ in range(nsets)]
-    nout_sets = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nsets)]
-    d_kps, d_desc, d_nout = kps_sets[0], desc_sets[0], nout_sets[0]
+    chain = DeviceChain(ROWS, COLS, B, nfeatures=NFEAT, nlevels=NLEVELS, device=local, nsets=nsets, th=7.0,
+                        check_orientation=True)
+    chain.load(seq)  # uploads the frames, extracts once, builds every frame's map points and the pair poses
+    ex, max_kp, npairs = chain.ex, chain.max_kp, chain.npairs
+    d_nout, d_nm = chain.nout[0], chain.d_nm
     s_ex = torch.cuda.current_stream()
     s_m = torch.cuda.Stream(device=dev) if args.overlap else s_ex
     stream = s_ex.cuda_stream
 
     def extract(s=0):
-        ex.extract_batch_device(d_img.data_ptr(), B, ROWS, COLS, kps_sets[s].data_ptr(), desc_sets[s].data_ptr(),
-                                nout_sets[s].data_ptr(), max_kp, stream=s_ex.cuda_stream)
-
-    extract()
-    torch.cuda.synchronize()
-    # map points of frame p: its keypoints back-projected at depth Z; the camera moves
-    # +t along x per frame so that the image content shifts 2 px per frame
-    fx = fy = 700.0
-    cx, cy, Z, tstep = COLS / 2.0, ROWS / 2.0, 10.0, 2.0 * 10.0 / 700.0
-    npairs = B - 1
-    kx, ky = d_kps[:npairs, :, 0], d_kps[:npairs, :, 1]
-    cam = (torch.arange(npairs, device=dev, dtype=torch.float32) * tstep)[:, None]
-    d_xw = torch.stack([(kx - cx) / fx * Z + cam, (ky - cy) / fy * Z, torch.full_like(kx, Z)], dim=2).contiguous()
-    idx = torch.arange(max_kp, device=dev)[None, :]
-    d_last_obs = torch.where(idx < d_nout[:npairs, None], 1, -1).to(torch.int32).contiguous()
-    d_cur_obs = torch.full((npairs, max_kp), -1, dtype=torch.int32, device=dev)
-    tcw = np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (npairs, 1))
-    tcw[:, 3] = -(np.arange(1, npairs + 1, dtype=np.float32) * np.float32(tstep))
-    d_tcw = torch.from_numpy(tcw).to(dev)
-    sf = ex.GetScaleFactors()
-    scratch_bytes = L.orb_match_scratch_bytes(npairs, max_kp)
-    d_scratch = torch.zeros(scratch_bytes, dtype=torch.uint8, device=dev)
-    d_match = torch.zeros((npairs, max_kp), dtype=torch.int32, device=dev)
-    d_nm = torch.zeros(npairs, dtype=torch.int32, device=dev)
-    bounds = FrameBounds(0.0, float(COLS), 0.0, float(ROWS))
-    kp_bytes = max_kp * 24
+        chain.extract(s, s_ex.cuda_stream)
 
     def match(s=0):
-        n, k, d = nout_sets[s].data_ptr(), kps_sets[s].data_ptr(), desc_sets[s].data_ptr()
-        check(L.orb_search_by_projection_frames_device(
-            local, npairs, max_kp, max_kp, d_tcw.data_ptr(), fx, fy, cx, cy, bounds, sf.ctypes.data, NLEVELS,
-            n, k, d_last_obs.data_ptr(), d_xw.data_ptr(), d,
-            n + 4, k + kp_bytes, d + max_kp * 32, d_cur_obs.data_ptr(),
-            7.0, 1, d_scratch.data_ptr(), scratch_bytes, d_match.data_ptr(), d_nm.data_ptr(), s_m.cuda_stream))
+        chain.match(s, s_m.cuda_stream)
 
     ex_done = [torch.cuda.Event() for _ in range(nsets)]
     m_done = [torch.cuda.Event() for _ in range(nsets)]
@@ -186,92 +158,145 @@ def main():
     nmatch = int(d_nm.sum().item())
     frames_per_s = world * B * args.steps / elapsed
 
+    # ---------------- host-buffer forms of the same extraction (rank 0, one GPU) ----------------
+    # value_pcie_inclusive: host images in, host keypoints out through orb_extract_batch (the same B
+    # frames); latency_ms_single_frame: one orb_extract call, the way Frame::ExtractORB calls the
+    # reference (src/Frame.cc:220-228), host to host, median.
+    host = None
+    if rank == 0 and world == 1 and args.host_reps > 0:
+        hk = np.zeros((B, max_kp), KP_DTYPE)
+        hd = np.zeros((B, max_kp, 32), np.uint8)
+        hn = np.zeros(B, np.int32)
+
+        def host_batch(n):
+            check(L.orb_extract_batch(ex._h, n, seq.ctypes.data, ROWS, COLS, COLS, ROWS * COLS, max_kp,
+                                      hk.ctypes.data, hd.ctypes.data, hn.ctypes.data))
+        host_batch(B)
+        tb = []
+        for _ in range(args.host_reps):
+            t = time.perf_counter(); host_batch(B); tb.append(time.perf_counter() - t)
+        host_batch(1)
+        tl = []
+        for _ in range(100):
+            t = time.perf_counter(); host_batch(1); tl.append(time.perf_counter() - t)
+        host = {"value_pcie_inclusive": round(B / float(np.median(tb)), 1),
+                "latency_ms_single_frame": round(1e3 * float(np.median(tl)), 4),
+                "latency_ms_single_frame_p90": round(1e3 * float(np.percentile(tl, 90)), 4)}
+        assert int(hn.sum()) == nkp, "host-buffer and device-buffer extraction disagree on the keypoint count"
+
     # ---------------- kNN-2 leg (C5 shape, database sharded over the ranks) ----------------
     knn = None
     if args.knn > 0:
         nq = ndb = args.knn
         db, q = synth_descriptors(ndb, nq, seed=1)
-        lo, hi = ndb * rank // world, ndb * (rank + 1) // world
+        lo, hi = odist.shard_bounds(ndb, world, rank)
         d_db = torch.from_numpy(db[lo:hi]).to(dev)
         d_q = torch.from_numpy(q).to(dev)
+        # the code path tests/test_dist_cpu.py runs with gloo: shard scan, one all-gather, merge
+        local_search = odist.hip_local_search(d_q, d_db, lo, 0.7, local, stream)
+        merge = odist.hip_merge(0.7, local, stream)
         res = torch.zeros((3, nq), dtype=torch.int32, device=dev)
-        gathered = torch.zeros((world, 3, nq), dtype=torch.int32, device=dev)
-        out = torch.zeros((3, nq), dtype=torch.int32, device=dev)
-        acc = torch.zeros(nq, dtype=torch.uint8, device=dev)
-
-        def knn_step():
-            check(L.orb_knn2_device(local, d_q.data_ptr(), nq, d_db.data_ptr(), hi - lo, lo, 0.7,
-                                    res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), None, stream))
-            if world > 1:
-                dist.all_gather_into_tensor(gathered, res)
-                g = gathered.permute(1, 0, 2).contiguous()  # [3][world][nq]
-            else:
-                g = res.view(3, 1, nq)
-            check(L.orb_knn2_merge_device(local, world, nq, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), 0.7,
-                                          out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), acc.data_ptr(), stream))
-
         small = min(nq, 65536)
         check(L.orb_knn2_device(local, d_q.data_ptr(), small, d_db.data_ptr(), min(hi - lo, 65536), lo, 0.7,
                                 res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), None, stream))  # warm-up
-        barrier()
-        tk0 = time.perf_counter()
-        knn_step()
-        barrier()
-        tk = torch.tensor([time.perf_counter() - tk0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
-        tk = float(tk.item())
+        times = []
+        for _ in range(max(args.knn_reps, 1)):
+            barrier()
+            tk0 = time.perf_counter()
+            out, acc = odist.knn2_sharded(local_search, merge, nq, dev, world)
+            barrier()
+            tk = torch.tensor([time.perf_counter() - tk0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+            times.append(float(tk.item()))
+        tk = float(np.median(times))
         pairs = float(nq) * float(ndb)
-        knn = {"n_query": nq, "n_database": ndb, "ratio": 0.7, "seconds": round(tk, 4),
+        knn = {"n_query": nq, "n_database": ndb, "ratio": 0.7, "seconds": round(tk, 4), "repetitions": len(times),
+               "seconds_all": [round(t, 4) for t in times],
                "matches_per_s": round(nq / tk, 1), "pairs_per_s": round(pairs / tk, 1),
                "accepted": int(acc.sum().item())}
-        if hi - lo >= 2048 and nq >= 256:
+        mfma = hi - lo >= 2048 and nq >= 256
+        if mfma:
             # the matrix-core kernel: one descriptor pair = 256 int8 multiply-adds
             knn["kernel"] = "knn2_mfma_kernel"
             knn["roofline"] = {"bound": "mfma", "achieved": round(512 * pairs / tk / 1e12, 1),
                                "peak": round(world * MFMA_I8_PEAK_OPS / 1e12, 1), "unit": "TOP/s",
                                "frac": round(512 * pairs / tk / (world * MFMA_I8_PEAK_OPS), 4)}
-        else:
-            # the popcount kernel: 16 vector instructions per pair
-            knn["kernel"] = "knn2_kernel"
-            knn["roofline"] = {"bound": "valu", "achieved": round(16 * pairs / tk / 1e12, 2),
-                               "peak": round(world * VALU_PEAK_LANEOPS / 1e12, 2), "unit": "T lane-ops/s",
-                               "frac": round(16 * pairs / tk / (world * VALU_PEAK_LANEOPS), 4)}
+        if not mfma or args.knn_popcount:
+            # the popcount kernel (what small inputs get): 16 vector instructions per pair, priced against
+            # the vector units' integer rate; run once on the same shard, results must be the same integers
+            r2 = torch.zeros((3, nq), dtype=torch.int32, device=dev)
+            barrier()
+            tp0 = time.perf_counter()
+            check(L.orb_knn2_device_algo(local, d_q.data_ptr(), nq, d_db.data_ptr(), hi - lo, lo, 0.7,
+                                         r2[0].data_ptr(), r2[1].data_ptr(), r2[2].data_ptr(), None, stream, 1))
+            barrier()
+            tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            tp = float(tp.item())
+            same = True
+            if mfma:
+                check(L.orb_knn2_device_algo(local, d_q.data_ptr(), nq, d_db.data_ptr(), hi - lo, lo, 0.7,
+                                             res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), None, stream, 2))
+                same = bool(torch.equal(res, r2))
+            pop = {"kernel": "knn2_kernel", "seconds": round(tp, 4), "matches_per_s": round(nq / tp, 1),
+                   "identical_to_mfma_kernel": same,
+                   "roofline": {"bound": "valu", "achieved": round(16 * pairs / tp / 1e12, 2),
+                                "peak": round(world * VALU_PEAK_LANEOPS / 1e12, 2), "unit": "T lane-ops/s",
+                                "frac": round(16 * pairs / tp / (world * VALU_PEAK_LANEOPS), 4)}}
+            if mfma:
+                knn["popcount"] = pop
+            else:
+                knn["kernel"] = "knn2_kernel"
+                knn["roofline"] = pop["roofline"]
 
-    # ---------------- CPU baseline (oracle, one core, rank 0, bounded sample) ----------------
+    # ---------------- CPU baseline (oracle, one core, rank 0, bounded sample) + parity of the timed chain ------------
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and args.cpu_frames > 1:
         from oracle import oracle as O
+        from oracle.chain_ref import chain_reference
         n = min(args.cpu_frames, B)
-        ref = O.Extractor(NFEAT, 1.2, NLEVELS, 20, 7)
         O.lib()
         tc0 = time.perf_counter()
-        prev = None
-        for k in range(n):
-            kps, desc = ref(seq[k])
-            if prev is not None:
-                pk, pd = prev
-                xw = np.stack([(pk["x"] - cx) / fx * Z + (k - 1) * tstep, (pk["y"] - cy) / fy * Z,
-                               np.full(len(pk), Z)], 1).astype(np.float32)
-                T = np.eye(4, dtype=np.float32)
-                T[0, 3] = -np.float32(k * tstep)
-                O.search_by_projection_frames(
-                    T, (fx, fy, cx, cy), (0.0, float(COLS), 0.0, float(ROWS)), sf,
-                    dict(mp_obs=np.ones(len(pk), np.int32), xw=xw, mp_desc=pd, octave=pk["octave"], angle=pk["angle"]),
-                    dict(x=kps["x"], y=kps["y"], octave=kps["octave"], angle=kps["angle"], desc=desc,
-                         obs=np.full(len(kps), -1, np.int32)), 7.0, True)
-            prev = (kps, desc)
+        frames, pairs_ref = chain_reference(chain.scene, seq[:n], NFEAT, NLEVELS)
         tc = time.perf_counter() - tc0
         cpu = {"value": round(n / tc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames of the same sequence: oracle extraction + SearchByProjection on consecutive pairs" % n}
+        # what the timed chain left on the GPU against what the oracle just computed for the same frames
+        g_nout, g_kps, g_desc, g_match, g_nm = chain.results((args.steps - 1) % nsets if args.steps > 0 else 0)
+        bad_frames = bad_pairs = 0
+        for k in range(n):
+            rk, rd = frames[k]
+            m = int(g_nout[k])
+            ok = m == len(rk) and all(np.array_equal(g_kps[k, :m][f], rk[f]) for f in ("x", "y", "octave", "response"))
+            ok = ok and np.abs(g_kps[k, :m]["angle"] - rk["angle"]).max() < 1e-4 * 180 / np.pi
+            ok = ok and (g_desc[k, :m] == rd).all(1).mean() >= 0.999
+            bad_frames += not ok
+        for p in range(n - 1):
+            m = int(g_nout[p + 1])
+            ok = int(g_nm[p]) == pairs_ref[p][0] and m == len(pairs_ref[p][1]) and np.array_equal(g_match[p, :m], pairs_ref[p][1])
+            bad_pairs += not ok
+        parity = {"parity_checked_frames": n, "parity_frame_mismatches": int(bad_frames),
+                  "parity_checked_pairs": n - 1, "parity_mismatches": int(bad_pairs)}
         if knn is not None:
             # the oracle's sequential kNN-2 on a slice of the same descriptors, reported per second of one core
             sq, sdb = q[:2000], db[:100000]
             tq0 = time.perf_counter()
-            O.knn2_bruteforce(sq, sdb, 0.7)
+            rb, rs, ri, ra = O.knn2_bruteforce(sq, sdb, 0.7)
             tq = time.perf_counter() - tq0
             knn["cpu_baseline"] = {"pairs_per_s": round(len(sq) * len(sdb) / tq, 1), "cores": 1, "kind": "port",
                                    "sample": "2000 queries x 100000 database rows of the same data"}
+            # and the same slice on the GPU, compared
+            gb = torch.zeros((3, len(sq)), dtype=torch.int32, device=dev)
+            ga = torch.zeros(len(sq), dtype=torch.uint8, device=dev)
+            check(L.orb_knn2_device(local, d_q.data_ptr(), len(sq), d_db.data_ptr(), len(sdb), 0, 0.7, gb[0].data_ptr(),
+                                    gb[1].data_ptr(), gb[2].data_ptr(), ga.data_ptr(), stream))
+            torch.cuda.synchronize()
+            gbn = gb.cpu().numpy()
+            knn["parity_checked_queries"] = len(sq)
+            knn["parity_mismatches"] = int((~((gbn[0] == rb) & (gbn[1] == rs) & (gbn[2] == ri) & (ga.cpu().numpy() == ra))).sum())
 
     if rank == 0:
         # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh + tools/pmc_to_traffic.py),
@@ -306,6 +331,10 @@ def main():
             "cpu_baseline": cpu,
             "knn2": knn,
         }
+        if host:
+            out.update(host)
+        if parity:
+            out.update(parity)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

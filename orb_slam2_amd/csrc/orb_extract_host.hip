@@ -338,11 +338,18 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
       auto refl = [](int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; };
       const int ncol = ti.ngx * TC;
       std::vector<int2> xr(ti.ngx, make_int2(1 << 30, -1)), yr(ti.ngy, make_int2(1 << 30, -1));
+      bool weights_ok = true;
       for (int c = 0; c < ncol; c++) {
         const int px = c - kXOff;
         uint32_t e = 0xFFFF0000u;
         if (c < L.pitch && px >= -kEdge && px < L.w + kEdge) {
           const XTab& t = xtab[L.xtab_off + refl(px, L.w)];
+          // the tiled kernel rebuilds the first weight as 2048 - a1.  cvRound((1.f - fx) * 2048)
+          // can differ from that only where 1.f - fx is inexact in float, i.e. in column 0 of a
+          // level, and then only if fx * 2048 lies within 2^-14 of a half-integer, which a
+          // fraction with a denominator below 8192 cannot do; a level where it happens anyway
+          // takes the generic kernel, which reads both weights
+          if ((int)t.a0 + (int)t.a1 != 2048) weights_ok = false;
           e = (uint32_t)t.sx | ((uint32_t)(uint16_t)t.a1 << 16);
           int2& r = xr[c / TC];
           r.x = std::min(r.x, (int)t.sx); r.y = std::max(r.y, (int)t.sx + 1);
@@ -354,7 +361,7 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
         int2& q = yr[r / TR];
         q.x = std::min(q.x, (int)std::min(t.sy0, t.sy1)); q.y = std::max(q.y, (int)std::max(t.sy0, t.sy1));
       }
-      ti.ok = true;
+      ti.ok = weights_ok;
       for (int2& r : xr) {
         if (r.y < 0) { r.x = 0; r.y = 0; }
         const int a0 = (r.x + kXOff) & ~15;

@@ -10,7 +10,7 @@
 // Work decomposition: a wavefront owns KM_QT tiles of 32 queries as the B operand, expanded
 // once into registers (KM_QT * 8 K-steps * 16 bytes per lane).  Database rows stream through
 // LDS 32 at a time: the workgroup expands the packed 32 x 32 bytes to 32 x 256 int8 (through a
-// byte -> 8 bytes table in LDS; double buffered, one barrier per tile) in the fragment order of
+// byte -> 8 bytes table in LDS; three buffers in turn, one barrier per tile) in the fragment order of
 // the A operand, every wavefront reads the eight A fragments (one ds_read_b128 each; the first
 // three are requested before the next tile is expanded, so that the MFMAs can start right after
 // the barrier) and issues 8 * KM_QT MFMAs.  In the
@@ -57,8 +57,9 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
                                                               float ratio, int* __restrict__ out_best,
                                                               int* __restrict__ out_second, int* __restrict__ out_idx,
                                                               uint8_t* __restrict__ out_accept) {
-  // A fragments of one 32-row tile: [group g = 2 * kstep + half][row][16 bytes], two buffers
-  __shared__ __attribute__((aligned(16))) km_v4i s_a[2][16 * 32];
+  // A fragments of one 32-row tile: [group g = 2 * kstep + half][row][16 bytes], three buffers
+  // used in turn (tile % 3)
+  __shared__ __attribute__((aligned(16))) km_v4i s_a[3][16 * 32];
   // 8 descriptor bits -> 8 bytes of +1 / -1; entry 256 (all zero) stands for rows past the end
   __shared__ __attribute__((aligned(8))) uint2 s_lut[257];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,30 +103,34 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
       pk0 = db16[o + eg0];
       pk1 = db16[o + eg0 + 8];
     };
-    // the packed rows in (pk0, pk1) go to buffer `tile & 1` as A fragments
-    auto expand = [&](int tile) {
+    // the packed rows in (pk0, pk1) go to buffer `tile % 3` as A fragments
+    auto expand = [&](int tile, int slot) {
       const bool v = tile * 32 + er < cn;
-      km_v4i* buf = s_a[tile & 1];
+      km_v4i* buf = s_a[slot];
       const uint2 a0 = s_lut[v ? (pk0 & 255u) : 256u], a1 = s_lut[v ? (pk0 >> 8) : 256u];
       const uint2 c0 = s_lut[v ? (pk1 & 255u) : 256u], c1 = s_lut[v ? (pk1 >> 8) : 256u];
       buf[eg0 * 32 + er] = km_v4i{(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
       buf[(eg0 + 8) * 32 + er] = km_v4i{(int)c0.x, (int)c0.y, (int)c1.x, (int)c1.y};
     };
-    // In iteration i the fragments of tile i (complete since the barrier of iteration i - 1)
-    // are requested first and tile i + 1 is expanded into the other buffer while they travel.
-    // A barrier waits for the LDS reads issued before it, so after the barrier of iteration
-    // i - 1 every wavefront holds tile i - 1 in registers and its buffer may be overwritten.
+    // In iteration i the first fragments of tile i (complete since the barrier of iteration
+    // i - 1) are requested, tile i + 1 is expanded into the next buffer while they travel, and
+    // the remaining fragments of tile i are read after the barrier.  A wavefront that runs ahead
+    // into iteration i + 1 writes tile i + 2, i.e. buffer (i + 2) % 3, which no read of tile i or
+    // i + 1 touches; it cannot get further ahead than that, because the barrier of iteration
+    // i + 1 waits for every wavefront to have finished iteration i.
     fetch(0);
-    expand(0);
+    expand(0, 0);
     if (ntiles > 1) fetch(1);
     __syncthreads();
+    int slot = 0;  // tile % 3
     for (int tile = 0; tile < ntiles; tile++) {
-      const km_v4i* buf = s_a[tile & 1];
+      const km_v4i* buf = s_a[slot];
+      slot = slot == 2 ? 0 : slot + 1;
       km_v4i a[8];  // the first KM_EARLY fragments before the barrier, the others behind the first MFMAs
 #pragma unroll
       for (int s = 0; s < KM_EARLY; s++) a[s] = buf[(2 * s + h) * 32 + r];
       if (tile + 1 < ntiles) {
-        expand(tile + 1);
+        expand(tile + 1, slot);
         if (tile + 2 < ntiles) fetch(tile + 2);  // in flight during the MFMAs
       }
       __syncthreads();
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
         }
       }
     }
-    __syncthreads();  // the next chunk starts writing buffer 0 again
+    __syncthreads();  // the next chunk starts writing buffer 0 again, which the last tiles may still be read from
     // lanes l and l + 32 hold the same queries over different rows
 #pragma unroll
     for (int t = 0; t < KM_QT; t++) {

@@ -65,3 +65,37 @@ def synth_descriptors(n_db, n_q, seed=1, max_flips=40):
         planted[m, b >> 3] ^= (1 << (b & 7)).astype(np.uint8)
     q[:n_plant] = planted
     return db, q
+
+
+class SequenceScene:
+    """Camera and map points that go with synth_sequence(rows, cols, n, step=2): a pinhole
+    camera translating +x by `tstep` per frame in front of a fronto-parallel scene at depth
+    Z, so that the image content moves 2 px per frame.  Frame p's map points are its own
+    keypoints back-projected to depth Z; projected with the pose of frame p + 1 they land
+    2 px to the left, which is what SearchByProjection(Cur = p + 1, Last = p) looks for.
+
+    All arithmetic is numpy float32 on the host, so that every consumer (benchmark, tests,
+    CPU baseline) builds bit-identical inputs from the same keypoints."""
+
+    def __init__(self, rows, cols):
+        self.rows, self.cols = int(rows), int(cols)
+        self.fx = self.fy = np.float32(700.0)
+        self.cx, self.cy = np.float32(cols / 2.0), np.float32(rows / 2.0)
+        self.Z = np.float32(10.0)
+        self.tstep = np.float32(2.0 * 10.0 / 700.0)
+        self.bounds = (0.0, float(cols), 0.0, float(rows))
+        self.K = (self.fx, self.fy, self.cx, self.cy)
+
+    def map_points(self, kx, ky, frame):
+        """World positions (n, 3) float32 of the keypoints (kx, ky) of frame `frame`."""
+        kx, ky = np.asarray(kx, np.float32), np.asarray(ky, np.float32)
+        cam = np.float32(frame) * self.tstep
+        x = (kx - self.cx) / self.fx * self.Z + cam
+        y = (ky - self.cy) / self.fy * self.Z
+        return np.stack([x, y, np.full_like(x, self.Z)], axis=-1).astype(np.float32)
+
+    def tcw(self, frame):
+        """Pose (4x4 float32, world -> camera) of frame `frame`."""
+        T = np.eye(4, dtype=np.float32)
+        T[0, 3] = -(np.float32(frame) * self.tstep)
+        return T

@@ -1,0 +1,155 @@
+"""GPU parity of the chain the benchmark times: orb_extract_batch_device followed by
+orb_search_by_projection_frames_device on the extractor's device-resident records (OrbKeyPoint
+strides, caller scratch, caller stream), against the CPU oracle of ORBextractor::operator()
+(reference src/ORBextractor.cc:1223-1339) and ORBmatcher::SearchByProjection(Cur, Last)
+(src/ORBmatcher.cc:1633-1788).  Integer results bit-exact; angles within 1e-4 rad."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROWS, COLS = 376, 1241
+
+
+def _run_chain(seq, nfeatures, ori, first_frame=0):
+    from orb_slam2_amd.chain import DeviceChain
+    ch = DeviceChain(ROWS, COLS, len(seq), nfeatures=nfeatures, check_orientation=ori)
+    ch.load(seq, first_frame)
+    ch.match(0)
+    return ch
+
+
+def _check_against_oracle(ch, seq, nfeatures, ori, first_frame=0):
+    from oracle.chain_ref import chain_reference, match_pair
+    nout, kps, desc, match, nm = ch.results()
+    frames, pairs = chain_reference(ch.scene, seq, nfeatures, first_frame=first_frame, check_ori=ori)
+    identical = True
+    for k, (rk, rd) in enumerate(frames):
+        n = int(nout[k])
+        assert n == len(rk) and n <= ch.max_kp, (k, n, len(rk))
+        g = kps[k, :n]
+        for f in ("x", "y", "octave", "response", "size"):
+            assert np.array_equal(g[f], rk[f]), (k, f)
+        assert np.abs(g["angle"] - rk["angle"]).max() < 1e-4 * 180 / np.pi
+        same = (desc[k, :n] == rd).all(1)
+        assert same.mean() >= 0.999
+        identical = identical and same.all() and np.array_equal(g["angle"], rk["angle"])
+    sf = ch.sf
+    for p in range(len(seq) - 1):
+        # the matcher on the GPU's own extraction: bit-exact whatever the float stages did
+        n0, n1 = int(nout[p]), int(nout[p + 1])
+        want_n, want_m = match_pair(ch.scene, sf, kps[p, :n0], desc[p, :n0], kps[p + 1, :n1], desc[p + 1, :n1],
+                                    first_frame + p, 7.0, ori)
+        assert nm[p] == want_n, (p, nm[p], want_n)
+        assert np.array_equal(match[p, :n1], want_m), p
+        assert (match[p, n1:] == -1).all()
+        if identical:  # then the oracle's whole chain gives the same matches too
+            assert pairs[p][0] == want_n and np.array_equal(pairs[p][1], want_m)
+    assert identical, "GPU angles / descriptors differ from the oracle's in the last bit somewhere"
+    return nm
+
+
+@pytest.mark.parametrize("n,ori", [(9, True), (7, False)])
+def test_extract_then_search_by_projection_on_device_records(n, ori):
+    from orb_slam2_amd.synth import synth_sequence
+    seq = synth_sequence(ROWS, COLS, n, seed=2000 + n, step=2)
+    ch = _run_chain(seq, 2000, ori)
+    nm = _check_against_oracle(ch, seq, 2000, ori)
+    assert (nm > 500).all(), nm  # the pairs really overlap
+    # a second call on the same scratch and outputs gives the same result
+    before = ch.results()
+    ch.match(0)
+    after = ch.results()
+    assert np.array_equal(before[3], after[3]) and np.array_equal(before[4], after[4])
+
+
+def test_device_matcher_equals_host_matcher_and_handles_ragged_pairs(oracle):
+    """Pairs with n_last < max_last, last-frame map points that are absent (-1), have no
+    observations (0) or have some (> 0), current keypoints already holding map points, on a
+    side stream; the device-record entry point against both the host-array one and the oracle."""
+    import torch
+    from helpers import kp_struct, projection_scene
+    from orb_slam2_amd import _lib
+    from orb_slam2_amd._lib import FrameBounds, check, ptr
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    npairs, max_last, max_cur = 5, 1100, 1300
+    rng = np.random.default_rng(77)
+    n_last = np.array([1100, 640, 1, 0, 997], np.int32)
+    n_cur = np.array([1300, 1300, 800, 900, 3], np.int32)
+    lk = np.zeros((npairs, max_last), _lib.KP_DTYPE)
+    ck = np.zeros((npairs, max_cur), _lib.KP_DTYPE)
+    lobs = np.full((npairs, max_last), -1, np.int32)
+    lxw = np.zeros((npairs, max_last, 3), np.float32)
+    ldesc = np.zeros((npairs, max_last, 32), np.uint8)
+    cdesc = np.zeros((npairs, max_cur, 32), np.uint8)
+    cobs = np.full((npairs, max_cur), -1, np.int32)
+    tcw = np.zeros((npairs, 16), np.float32)
+    wants, scs = [], []
+    for p in range(npairs):
+        nl, nc = int(n_last[p]), int(n_cur[p])
+        sc = projection_scene(rng, max(nl, 1), nc, ROWS, COLS, conflict_clusters=8 if nc > 100 else 0)
+        for k in sc["last"]:
+            sc["last"][k] = sc["last"][k][:nl]
+        scs.append(sc)
+        la, cu = sc["last"], sc["cur"]
+        lk[p, :nl] = kp_struct(np.zeros(nl), np.zeros(nl), la["octave"], la["angle"])
+        ck[p, :nc] = kp_struct(cu["x"], cu["y"], cu["octave"], cu["angle"])
+        lobs[p, :nl], lxw[p, :nl], ldesc[p, :nl] = la["mp_obs"], la["xw"], la["mp_desc"]
+        cdesc[p, :nc], cobs[p, :nc] = cu["desc"], cu["obs"]
+        tcw[p] = sc["Tcw"].reshape(16)
+        wants.append(oracle.search_by_projection_frames(sc["Tcw"], sc["K"], sc["bounds"], sc["sf"], la, cu, 7.0, True))
+    assert {-1, 0}.issubset(set(np.unique(lobs))) and lobs.max() > 0
+    K, b, sf = scs[0]["K"], scs[0]["bounds"], scs[0]["sf"]
+    bounds = FrameBounds(*b)
+    up = lambda a: torch.from_numpy(a).to(dev)
+    d = dict(tcw=up(tcw), nl=up(n_last), lk=up(lk.view(np.uint8)), lobs=up(lobs), lxw=up(lxw), ldesc=up(ldesc),
+             nc=up(n_cur), ck=up(ck.view(np.uint8)), cdesc=up(cdesc), cobs=up(cobs))
+    nbytes = L.orb_match_scratch_bytes(npairs, max_last)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    d_match = torch.full((npairs, max_cur), 12345, dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(npairs, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for _ in range(2):  # the second call reuses the scratch as the first one left it
+        check(L.orb_search_by_projection_frames_device(
+            0, npairs, max_last, max_cur, d["tcw"].data_ptr(), float(K[0]), float(K[1]), float(K[2]), float(K[3]),
+            bounds, sf.ctypes.data, 8, d["nl"].data_ptr(), d["lk"].data_ptr(), d["lobs"].data_ptr(),
+            d["lxw"].data_ptr(), d["ldesc"].data_ptr(), d["nc"].data_ptr(), d["ck"].data_ptr(), d["cdesc"].data_ptr(),
+            d["cobs"].data_ptr(), 7.0, 1, scratch.data_ptr(), nbytes, d_match.data_ptr(), d_nm.data_ptr(),
+            side.cuda_stream))
+        side.synchronize()
+        got_m, got_n = d_match.cpu().numpy(), d_nm.cpu().numpy()
+        for p in range(npairs):
+            nc = int(n_cur[p])
+            assert got_n[p] == wants[p][0], p
+            assert np.array_equal(got_m[p, :nc], wants[p][1]), p
+    # the host-array entry point on the same data
+    hm = np.zeros((npairs, max_cur), np.int32)
+    hn = np.zeros(npairs, np.int32)
+    f32, i32 = np.float32, np.int32
+    arrs = [n_last, lobs, lxw, ldesc, np.ascontiguousarray(lk["octave"], i32), np.ascontiguousarray(lk["angle"], f32),
+            n_cur, np.ascontiguousarray(ck["x"], f32), np.ascontiguousarray(ck["y"], f32),
+            np.ascontiguousarray(ck["octave"], i32), np.ascontiguousarray(ck["angle"], f32), cdesc, cobs]
+    check(L.orb_search_by_projection_frames(0, npairs, max_last, max_cur, ptr(tcw), float(K[0]), float(K[1]),
+                                            float(K[2]), float(K[3]), bounds, ptr(sf), 8, *[ptr(a) for a in arrs],
+                                            7.0, 1, ptr(hm), ptr(hn)))
+    assert np.array_equal(hn, got_n)
+    for p in range(npairs):
+        assert np.array_equal(hm[p, :n_cur[p]], got_m[p, :n_cur[p]])
+
+
+def test_scratch_too_small_is_rejected():
+    import torch
+    from orb_slam2_amd import _lib
+    from orb_slam2_amd._lib import FrameBounds
+    L = _lib.lib()
+    t = torch.zeros(4096, dtype=torch.uint8, device="cuda:0")
+    sf = np.ones(8, np.float32)
+    p = t.data_ptr()
+    rc = L.orb_search_by_projection_frames_device(0, 4, 2000, 2000, p, 1.0, 1.0, 0.0, 0.0, FrameBounds(0, 1, 0, 1),
+                                                  sf.ctypes.data, 8, p, p, p, p, p, p, p, p, p, 7.0, 1, p, 4096, p, p,
+                                                  None)
+    assert rc == _lib.ERR_CAPACITY

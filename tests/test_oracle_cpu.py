@@ -87,6 +87,40 @@ def test_resize_constant_ramp_and_coefficients(oracle):
             assert out[dy, dx] == want
 
 
+def test_resize_weight_pairs_sum_to_2048_for_every_level_width():
+    """cv::resize rounds both bilinear weights on their own: a0 = cvRound((1.f - fx) * 2048),
+    a1 = cvRound(fx * 2048) (the call is at reference src/ORBextractor.cc:1367-1372).  The tiled
+    resize kernel keeps a1 and rebuilds a0 as 2048 - a1, which is the same number unless
+    1.f - fx is inexact in float; the host code sends a level to the generic kernel (both weights
+    read) if a column ever disagrees.  This sweep shows that no level of any supported image
+    width (62 .. 4127 px) at scale 1.2 has such a column, so the tiled kernel is what runs."""
+    def axis(dn, sn):
+        scale = 1.0 / (float(dn) / sn)
+        fx = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(fx)
+        fx = (fx - s).astype(np.float32)
+        a0 = np.rint((np.float32(1) - fx).astype(np.float32) * np.float32(2048)).astype(np.int64)
+        a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+        return s.astype(np.int64), a0, a1
+
+    sf, _ = scale_tables()
+    inv = (np.float32(1) / sf).astype(np.float32)
+    off = []
+    for cols in range(62, 4128):
+        w = [int(np.rint(np.float32(cols) * inv[l])) for l in range(8)]
+        for l in range(1, 8):
+            if w[l] < 62:
+                break
+            s, a0, a1 = axis(w[l], w[l - 1])
+            inside = (s >= 0) & (s < w[l - 1] - 1)  # clamped columns get (2048, 0) on the host
+            if ((a0 + a1 != 2048) & inside).any():
+                off.append((cols, l))
+    assert off == []
+    # the sum can only leave 2048 by one, and only through the rounding of 1.f - fx
+    s, a0, a1 = axis(1000, 1499)
+    assert set(np.unique(a0 + a1)) <= {2047, 2048, 2049}
+
+
 def test_border_reflect101(oracle):
     a = np.arange(30, dtype=np.uint8).reshape(5, 6) * 3
     p = oracle.copy_make_border_101(a, 3)
