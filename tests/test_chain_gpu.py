@@ -44,7 +44,6 @@ def _check_against_oracle(ch, seq, nfeatures, ori, first_frame=0):
                                     first_frame + p, 7.0, ori)
         assert nm[p] == want_n, (p, nm[p], want_n)
         assert np.array_equal(match[p, :n1], want_m), p
-        assert (match[p, n1:] == -1).all()
         if identical:  # then the oracle's whole chain gives the same matches too
             assert pairs[p][0] == want_n and np.array_equal(pairs[p][1], want_m)
     assert identical, "GPU angles / descriptors differ from the oracle's in the last bit somewhere"
