@@ -1071,23 +1071,17 @@ size_t orb_match_scratch_bytes(int n_pairs, int max_queries) {
   return (size_t)n_pairs * max_queries * kScratchPerQuery + 64;
 }
 
-int orb_search_by_projection_frames_device(int device_id, int n_pairs, int max_last, int max_cur, const float* d_tcw,
-                                           float fx, float fy, float cx, float cy, OrbFrameBounds bounds,
-                                           const float* scale_factors, int nlevels, const int* d_n_last,
-                                           const OrbKeyPoint* d_last_kps, const int* d_last_mp_obs,
-                                           const float* d_last_xw, const uint8_t* d_last_mp_desc, const int* d_n_cur,
-                                           const OrbKeyPoint* d_cur_kps, const uint8_t* d_cur_desc,
-                                           const int* d_cur_obs, float th, int check_orientation, void* d_scratch,
-                                           size_t scratch_bytes, int* d_cur_match, int* d_n_matches, void* stream) {
-  if (n_pairs <= 0) return ORBHIP_OK;
-  if (max_last <= 0 || max_cur <= 0 || max_cur > 65535 || nlevels < 1 || nlevels > kMaxLevels) { set_error("size out of range"); return ORBHIP_ERR_ARG; }
-  if (!d_tcw || !scale_factors || !d_n_last || !d_last_kps || !d_last_mp_obs || !d_last_xw || !d_last_mp_desc ||
-      !d_n_cur || !d_cur_kps || !d_cur_desc || !d_cur_obs || !d_scratch || !d_cur_match || !d_n_matches) {
-    set_error("null argument"); return ORBHIP_ERR_ARG;
-  }
-  if (scratch_bytes < orb_match_scratch_bytes(n_pairs, max_last)) { set_error("scratch too small"); return ORBHIP_ERR_CAPACITY; }
-  if (((uintptr_t)d_last_mp_desc | (uintptr_t)d_cur_desc | (uintptr_t)d_scratch) & 15) { set_error("descriptor and scratch arrays must be 16-byte aligned"); return ORBHIP_ERR_ARG; }
-  DevSel g(device_id);
+// Shared body of the two device-record forms below: argument checks, the MatchArgs of
+// MODE_FRAMES on OrbKeyPoint records, launch on the caller's stream.  `scratch` is a device
+// address holding orb_match_scratch_bytes(n_pairs, max_last) bytes.
+static int frames_device_launch(int n_pairs, int max_last, int max_cur, const float* d_tcw, float fx, float fy, float cx,
+                                float cy, OrbFrameBounds bounds, const float* scale_factors, int nlevels,
+                                const int* d_n_last, const OrbKeyPoint* d_last_kps, const int* d_last_mp_obs,
+                                const float* d_last_xw, const uint8_t* d_last_mp_desc, const int* d_n_cur,
+                                const OrbKeyPoint* d_cur_kps, const uint8_t* d_cur_desc, const int* d_cur_obs, float th,
+                                int check_orientation, void* scratch, int* d_cur_match, int* d_n_matches,
+                                hipStream_t stream) {
+  if (((uintptr_t)d_last_mp_desc | (uintptr_t)d_cur_desc | (uintptr_t)scratch) & 15) { set_error("descriptor and scratch arrays must be 16-byte aligned"); return ORBHIP_ERR_ARG; }
   MatchArgs A{};
   A.max_q = max_last; A.max_t = max_cur; A.nlevels = nlevels; A.check_ori = check_orientation;
   A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.b = bounds; A.th = th;
@@ -1101,8 +1095,34 @@ int orb_search_by_projection_frames_device(int device_id, int n_pairs, int max_l
   A.t_x = ck; A.t_y = ck + 1; A.t_angle = ck + 3; A.t_oct = reinterpret_cast<const int*>(ck) + 5;
   A.t_desc = d_cur_desc; A.t_obs = d_cur_obs;
   A.out_match = d_cur_match; A.n_matches = d_n_matches;
-  carve_scratch(A, d_scratch, (size_t)n_pairs * max_last);
-  return launch_match<MODE_FRAMES>(A, n_pairs, (hipStream_t)stream);
+  carve_scratch(A, scratch, (size_t)n_pairs * max_last);
+  return launch_match<MODE_FRAMES>(A, n_pairs, stream);
+}
+
+static bool frames_device_args_ok(int max_last, int max_cur, int nlevels, const void* const* ptrs, int nptrs) {
+  if (max_last <= 0 || max_cur <= 0 || max_cur > 65535 || nlevels < 1 || nlevels > kMaxLevels) { set_error("size out of range"); return false; }
+  for (int i = 0; i < nptrs; i++)
+    if (!ptrs[i]) { set_error("null argument"); return false; }
+  return true;
+}
+
+int orb_search_by_projection_frames_device(int device_id, int n_pairs, int max_last, int max_cur, const float* d_tcw,
+                                           float fx, float fy, float cx, float cy, OrbFrameBounds bounds,
+                                           const float* scale_factors, int nlevels, const int* d_n_last,
+                                           const OrbKeyPoint* d_last_kps, const int* d_last_mp_obs,
+                                           const float* d_last_xw, const uint8_t* d_last_mp_desc, const int* d_n_cur,
+                                           const OrbKeyPoint* d_cur_kps, const uint8_t* d_cur_desc,
+                                           const int* d_cur_obs, float th, int check_orientation, void* d_scratch,
+                                           size_t scratch_bytes, int* d_cur_match, int* d_n_matches, void* stream) {
+  if (n_pairs <= 0) return ORBHIP_OK;
+  const void* ptrs[] = {d_tcw, scale_factors, d_n_last, d_last_kps, d_last_mp_obs, d_last_xw, d_last_mp_desc,
+                        d_n_cur, d_cur_kps, d_cur_desc, d_cur_obs, d_scratch, d_cur_match, d_n_matches};
+  if (!frames_device_args_ok(max_last, max_cur, nlevels, ptrs, (int)(sizeof(ptrs) / sizeof(ptrs[0])))) return ORBHIP_ERR_ARG;
+  if (scratch_bytes < orb_match_scratch_bytes(n_pairs, max_last)) { set_error("scratch too small"); return ORBHIP_ERR_CAPACITY; }
+  DevSel g(device_id);
+  return frames_device_launch(n_pairs, max_last, max_cur, d_tcw, fx, fy, cx, cy, bounds, scale_factors, nlevels, d_n_last,
+                              d_last_kps, d_last_mp_obs, d_last_xw, d_last_mp_desc, d_n_cur, d_cur_kps, d_cur_desc,
+                              d_cur_obs, th, check_orientation, d_scratch, d_cur_match, d_n_matches, (hipStream_t)stream);
 }
 
 int orb_search_by_projection_mappoints(int device_id, OrbFrameBounds bounds, const float* scale_factors, int nlevels,
