@@ -216,6 +216,25 @@ int orb_search_by_projection_frames_device(
     int check_orientation, void* d_scratch, size_t scratch_bytes, int* d_cur_match,
     int* d_n_matches, void* stream);
 
+/* The same search as orb_search_by_projection_frames_device for callers that must not
+ * allocate and have no workspace to hand over (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The per-query work
+ * arrays live in a fixed array inside the library, ORBHIP_NOALLOC_MAX_QUERIES * 60 + 64 bytes
+ * (3.75 MiB) on every GPU the library is used on, held until the process ends; the call fails
+ * with ORBHIP_ERR_CAPACITY if n_pairs * max_last exceeds ORBHIP_NOALLOC_MAX_QUERIES.  It calls no
+ * hipMalloc / hipFree; the first call on a device looks the array's address up once.  All calls
+ * on one GPU share that array: calls that overlap in time on one GPU (different streams or
+ * threads) race and must be serialised by the caller.  Inputs, outputs and results as in
+ * orb_search_by_projection_frames_device. */
+#define ORBHIP_NOALLOC_MAX_QUERIES 65536
+int orb_search_by_projection_frames_noalloc(
+    int device_id, int n_pairs, int max_last, int max_cur, const float* d_tcw, float fx, float fy,
+    float cx, float cy, OrbFrameBounds bounds, const float* scale_factors, int nlevels,
+    const int* d_n_last, const OrbKeyPoint* d_last_kps, const int* d_last_mp_obs,
+    const float* d_last_xw, const uint8_t* d_last_mp_desc, const int* d_n_cur,
+    const OrbKeyPoint* d_cur_kps, const uint8_t* d_cur_desc, const int* d_cur_obs, float th,
+    int check_orientation, int* d_cur_match, int* d_n_matches, void* stream);
+
 /* ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>&, th)
  * (src/ORBmatcher.cc:64-158) for one frame.  Per map point: mp_track =
  * mbNeedTrackInView && !isBad(), mnTrackedScaleLevel, mTrackedViewCosine,

@@ -36,7 +36,7 @@ EXPORTS = [
     "orb_extractor_get_scale_tables", "orb_extractor_get_level_quotas", "orb_extractor_max_keypoints",
     "orb_extract", "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync",
     "orb_extractor_set_profiling", "orb_extractor_set_input_format", "orb_extractor_stage_times", "orb_match_scratch_bytes",
-    "orb_search_by_projection_frames_device", "orb_match_windowed", "orb_stereo_match", "orb_search_by_bow", "orb_window_best", "orb_search_for_initialization",
+    "orb_search_by_projection_frames_device", "orb_search_by_projection_frames_noalloc", "orb_match_windowed", "orb_stereo_match", "orb_search_by_bow", "orb_window_best", "orb_search_for_initialization",
     "orb_get_pyramid_level", "orb_get_blurred_level", "orb_get_fast_candidates", "orb_get_level_keypoints",
     "orb_hamming_distance_pairs", "orb_search_by_projection_frames", "orb_search_by_projection_mappoints",
     "orb_search_for_triangulation", "orb_knn2_device", "orb_knn2_device_algo", "orb_knn2_merge_device", "orb_knn2_bruteforce",
@@ -79,6 +79,8 @@ def lib():
     L.orb_match_scratch_bytes.restype = sz
     L.orb_search_by_projection_frames_device.argtypes = (
         [i, i, i, i, vp, f, f, f, f, FrameBounds, vp, i] + [vp] * 9 + [f, i, vp, sz, vp, vp, vp])
+    L.orb_search_by_projection_frames_noalloc.argtypes = (
+        [i, i, i, i, vp, f, f, f, f, FrameBounds, vp, i] + [vp] * 9 + [f, i, vp, vp, vp])
     L.orb_get_pyramid_level.argtypes = [vp, i, i, i, vp, sz, C.POINTER(i), C.POINTER(i)]
     L.orb_get_blurred_level.argtypes = [vp, i, i, vp, sz, C.POINTER(i), C.POINTER(i)]
     L.orb_get_fast_candidates.argtypes = [vp, i, i, i, vp]

@@ -7,6 +7,7 @@
 // reference's sequential scan would rank them) and a short ordered phase that
 // replays the reference's query order on those lists, 64 queries per step.
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "orb_common.h"
@@ -950,6 +951,34 @@ int bucket_queries(int n1, int n2, int n_nodes1, const int* node1, const int* st
 
 }  // namespace orbhip
 
+// Scratch of orb_search_by_projection_frames_noalloc: the per-query work arrays of match_kernel
+// (window geometry, ranked candidate lists, counts, chosen slot, rotation bin) for up to
+// ORBHIP_NOALLOC_MAX_QUERIES queries.  Every GPU the library runs on holds its own copy of this
+// array at its own address until the process ends.  In host code the name below is only a handle
+// for hipGetSymbolAddress; kernels and copies get the address that call returned.
+static __device__ __align__(256) unsigned char scratch[(size_t)ORBHIP_NOALLOC_MAX_QUERIES * orbhip::kScratchPerQuery + 64];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, 0 = not asked yet
+
+// Address of `scratch` on the current device `dev`, looked up once per device.
+int noalloc_scratch_address(int dev, void** out) {
+  if (dev < 0 || dev >= kMaxDevices) { orbhip::set_error("device index out of range"); return ORBHIP_ERR_ARG; }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return orbhip::hip_fail(e, "hipGetSymbolAddress(scratch)");
+    if (!p) { orbhip::set_error("hipGetSymbolAddress returned a null address"); return ORBHIP_ERR_HIP; }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return ORBHIP_OK;
+}
+}  // namespace
+
 using namespace orbhip;
 
 extern "C" {
@@ -1123,6 +1152,35 @@ int orb_search_by_projection_frames_device(int device_id, int n_pairs, int max_l
   return frames_device_launch(n_pairs, max_last, max_cur, d_tcw, fx, fy, cx, cy, bounds, scale_factors, nlevels, d_n_last,
                               d_last_kps, d_last_mp_obs, d_last_xw, d_last_mp_desc, d_n_cur, d_cur_kps, d_cur_desc,
                               d_cur_obs, th, check_orientation, d_scratch, d_cur_match, d_n_matches, (hipStream_t)stream);
+}
+
+int orb_search_by_projection_frames_noalloc(int device_id, int n_pairs, int max_last, int max_cur, const float* d_tcw,
+                                            float fx, float fy, float cx, float cy, OrbFrameBounds bounds,
+                                            const float* scale_factors, int nlevels, const int* d_n_last,
+                                            const OrbKeyPoint* d_last_kps, const int* d_last_mp_obs,
+                                            const float* d_last_xw, const uint8_t* d_last_mp_desc, const int* d_n_cur,
+                                            const OrbKeyPoint* d_cur_kps, const uint8_t* d_cur_desc,
+                                            const int* d_cur_obs, float th, int check_orientation, int* d_cur_match,
+                                            int* d_n_matches, void* stream) {
+  if (n_pairs <= 0) return ORBHIP_OK;
+  const void* ptrs[] = {d_tcw, scale_factors, d_n_last, d_last_kps, d_last_mp_obs, d_last_xw, d_last_mp_desc,
+                        d_n_cur, d_cur_kps, d_cur_desc, d_cur_obs, d_cur_match, d_n_matches};
+  if (!frames_device_args_ok(max_last, max_cur, nlevels, ptrs, (int)(sizeof(ptrs) / sizeof(ptrs[0])))) return ORBHIP_ERR_ARG;
+  if ((long long)n_pairs * max_last > ORBHIP_NOALLOC_MAX_QUERIES) {
+    set_error("n_pairs * max_last = " + std::to_string((long long)n_pairs * max_last) +
+              " exceeds the built-in scratch of ORBHIP_NOALLOC_MAX_QUERIES = " +
+              std::to_string(ORBHIP_NOALLOC_MAX_QUERIES) + " queries; use orb_search_by_projection_frames_device");
+    return ORBHIP_ERR_CAPACITY;
+  }
+  DevSel g(device_id);
+  void* sp = nullptr;
+  int rc = noalloc_scratch_address(device_id, &sp);
+  if (rc != ORBHIP_OK) return rc;
+  // nothing in the scratch has to start at zero: the kernel writes every entry of a pair's
+  // slice before it reads it
+  return frames_device_launch(n_pairs, max_last, max_cur, d_tcw, fx, fy, cx, cy, bounds, scale_factors, nlevels, d_n_last,
+                              d_last_kps, d_last_mp_obs, d_last_xw, d_last_mp_desc, d_n_cur, d_cur_kps, d_cur_desc,
+                              d_cur_obs, th, check_orientation, sp, d_cur_match, d_n_matches, (hipStream_t)stream);
 }
 
 int orb_search_by_projection_mappoints(int device_id, OrbFrameBounds bounds, const float* scale_factors, int nlevels,
