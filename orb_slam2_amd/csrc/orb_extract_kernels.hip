@@ -335,6 +335,12 @@ __device__ __forceinline__ bool fast_nms_keep(const uint8_t* q, int v, bool hasL
   return v > max(mc, max(ml, mr));
 }
 
+// Exact floor(off / F_PITCH) for off < 32768 and floor(n / d) for n, d < 256 with m = 65536 / d + 1,
+// by multiplication (checked exhaustively on the host side of the tests).
+static_assert(F_PITCH == 272, "div_pitch's constant is for a pitch of 272");
+__device__ __forceinline__ int div_pitch(int off) { return (int)(((uint32_t)off * 61681u) >> 24); }
+__device__ __forceinline__ int div_small(int n, int m) { return (n * m) >> 16; }
+
 __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
                                                          const FastItem* __restrict__ items,
                                                          uint32_t* __restrict__ cand_all,
@@ -344,8 +350,10 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   uint8_t* const s_img = s_dyn;
   uint8_t* const s_v = s_dyn + lds_rows * F_PITCH;
-  __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];    // per wavefront: quick-test survivors (row << 8 | column)
-  __shared__ uint16_t s_corner[F_THREADS / 64][F_CCAP];  // per wavefront: corners (V > t) found so far
+  // per wavefront: quick-test survivors and corners (V > t), both as the pixel's byte offset in
+  // the staged view (bit 15 of a survivor: test the darker ring only)
+  __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];
+  __shared__ uint16_t s_corner[F_THREADS / 64][F_CCAP];
   __shared__ int s_ncorner[F_THREADS / 64];
   __shared__ int s_cnt[F_MAXCELLS];
   __shared__ int s_total, s_base, s_emit;
@@ -357,6 +365,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const LevelGeom& L = P.lv[item.level];
   const int wCell = L.wCell, hCell = L.hCell;
+  const int wCellM = 65536 / wCell + 1;  // div_small(n, wCellM) = n / wCell
   const int iniY = kBorder + item.row * hCell;
   const int maxY = min(iniY + hCell + 6, L.maxBY);
   const int xb = kBorder + item.j0 * wCell;
@@ -401,21 +410,29 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   auto below = [](unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
   };
+  uint32_t* out = cand_all + (size_t)f * P.cand_total + L.cand_off;
+  int* const out_cnt = &cand_cnt[f * P.nlevels + item.level];
+  // level coordinates (relative to the border origin) and record of the pixel at byte offset off
+  auto record = [&](int off, int ey, int v) {
+    const int ex = off - ey * F_PITCH - xoff;
+    const int xr = xb + 3 + ex - kBorder, yr = iniY + ey - kBorder;  // ey counts staged rows: interior row + 3
+    return (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
+  };
   unsigned cellmask = (1u << item.ncells) - 1;  // cells to (re)compute in this pass
-  int ncorner = 0;                              // wave-uniform: entries in this wave's corner list
-  bool overflow = false;                        // wave-uniform: corner list too small, sweep densely
   for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? iniTh : minTh;
-    int qn = 0;  // wave-uniform: entries waiting in this wave's queue
+    int qn = 0;             // wave-uniform: entries waiting in this wave's queue
+    int ncorner = 0;        // wave-uniform: entries in this wave's corner list
+    bool overflow = false;  // wave-uniform: corner list too small, sweep densely
 
-    // full test of queue entries [0, n) (n <= 64 per call chunk), corners appended
+    // full test of queue entries [head, head + n) (n <= 64), corners appended
     auto drain = [&](int head, int n) {
       const int k = head + lane;
       bool corner = false, again = false;
       int e = 0;
       if (lane < n) {
         e = s_list[wave][k];
-        const int off = (((e >> 8) & 0x7F) + 3) * F_PITCH + (e & 0xFF);
+        const int off = e & 0x7FFF;
         const int v = fast_v1(&s_img[off], t, (e & 0x8000) != 0, again);
         corner = v > t;
         if (corner) s_v[off] = (uint8_t)v;  // the V map starts at 0 (staging, or the clearing before pass 2)
@@ -429,16 +446,15 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
           qn += __popcll(ma);
         } else if (again) {  // no room left in the queue: the second polarity right here
           bool unused;
-          const int off = (((e >> 8) & 0x7F) + 3) * F_PITCH + (e & 0xFF);
+          const int off = e & 0x7FFF;
           const int v = fast_v1(&s_img[off], t, true, unused);
           if (v > t) { corner = true; s_v[off] = (uint8_t)v; }
         }
       }
-      e &= 0x7FFF;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);
       const int nc = __popcll(m);
       if (ncorner + nc > F_CCAP) overflow = true;
-      else if (corner) s_corner[wave][ncorner + below(m)] = (uint16_t)e;
+      else if (corner) s_corner[wave][ncorner + below(m)] = (uint16_t)(e & 0x7FFF);
       if (!overflow) ncorner += nc;
     };
 
@@ -472,7 +488,8 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         const int y = min(yb + sub, hi - 1);
         const bool vy = yb + sub < hi;
         const unsigned long long row_mask = __builtin_amdgcn_ballot_w64(vy);
-        const uint8_t* rowp = &s_img[(y + 3) * F_PITCH + col4];
+        const int rowoff = (y + 3) * F_PITCH + col4;  // byte offset of the lane's first pixel
+        const uint8_t* rowp = &s_img[rowoff];
         const uint32_t C = *reinterpret_cast<const uint32_t*>(rowp);
         const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4);
         const uint32_t R = *reinterpret_cast<const uint32_t*>(rowp + 4);
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
           // predicate would be rebuilt from a select and a compare)
           const unsigned long long m =
               (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & mine_mask[j] & row_mask;
-          if (ok) s_list[wave][qn + below(m)] = (uint16_t)((y << 8) | (col4 + j));
+          if (ok) s_list[wave][qn + below(m)] = (uint16_t)(rowoff + j);
           qn += __popcll(m);
         }
         if (qn >= 64) {
@@ -517,120 +534,83 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     }
     if (lane == 0) s_ncorner[wave] = overflow ? -1 : ncorner;
     __syncthreads();
-    // ---- cell-local NMS, count per cell: over the corner lists (or densely on overflow)
+    // ---- cell-local NMS over the corner lists; a corner that survives is counted for its cell
+    // and written out at once (a cell that is computed again in the second pass has, by
+    // definition, no survivor in the first).  Each wavefront reserves room for the survivors
+    // of 64 corners with one atomic of its own; the order within a level's list is arbitrary,
+    // the quad-tree kernel does not depend on it.
     bool any_overflow = false;
 #pragma unroll
     for (int w = 0; w < F_THREADS / 64; w++) any_overflow |= s_ncorner[w] < 0;
     if (!any_overflow) {
-      for (int k = lane; k < ncorner; k += 64) {
-        const int e = s_corner[wave][k];
-        const int ex = (e & 0xFF) - xoff, ey = (e >> 8) & 0x7F;
-        const int ecj = ex / wCell, exc = ex - ecj * wCell;
-        if (!((cellmask >> ecj) & 1u)) continue;
-        const uint8_t* q = &s_v[(ey + 3) * F_PITCH + (e & 0xFF)];
+      for (int k0 = 0; k0 < ncorner; k0 += 64) {  // uniform
+        const int k = k0 + lane;
+        const int off = k < ncorner ? (int)s_corner[wave][k] : 3 * F_PITCH + 4;
+        const int ey = div_pitch(off);
+        const int ex = off - ey * F_PITCH - xoff;
+        const int ecj = div_small(ex, wCellM), exc = ex - ecj * wCell;
+        const uint8_t* q = &s_v[off];
         const int v = q[0];
-        if (v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1)) {
-          atomicAdd(&s_cnt[ecj], 1);
-          s_corner[wave][k] = (uint16_t)(e | 0x8000);  // bit 15: survives the suppression, goes out
+        const bool keep = k < ncorner && v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1);
+        if (keep) atomicAdd(&s_cnt[ecj], 1);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (m) {
+          int wbase = 0;
+          if (lane == 0) wbase = atomicAdd(out_cnt, __popcll(m));
+          wbase = __builtin_amdgcn_readfirstlane(wbase);
+          const int slot = wbase + below(m);
+          if (keep && slot < L.cand_cap) out[slot] = record(off, ey, v);
         }
       }
+      __syncthreads();
     } else {
-      const int x = tid;  // dense sweep: a thread per interior column
-      if (x < wi && ((cellmask >> (x / wCell)) & 1u)) {
-        const int cj = x / wCell, xc = x - cj * wCell;
+      // a corner list overflowed: dense sweep of the V map, a thread per interior column;
+      // count, one reservation for the workgroup, then the same sweep writes
+      const int x = tid;
+      const bool mycol = x < wi && ((cellmask >> div_small(x, wCellM)) & 1u);
+      const int cj = div_small(min(x, wi - 1), wCellM), xc = x - cj * wCell;
+      if (tid == 0) { s_total = 0; s_emit = 0; }
+      __syncthreads();
+      if (mycol) {
         int n = 0;
         for (int y = 0; y < hi; y++) {
           const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + xoff];
           const int v = q[0];
           if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) n++;
         }
-        if (n) atomicAdd(&s_cnt[cj], n);
+        if (n) { atomicAdd(&s_cnt[cj], n); atomicAdd(&s_total, n); }
       }
+      __syncthreads();
+      if (tid == 0) s_base = s_total ? atomicAdd(out_cnt, s_total) : 0;
+      __syncthreads();
+      if (mycol && s_total) {
+        const int gbase = s_base;
+        for (int y = 0; y < hi; y++) {
+          const int off = (y + 3) * F_PITCH + x + xoff;
+          const uint8_t* q = &s_v[off];
+          const int v = q[0];
+          if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) {
+            const int slot = gbase + atomicAdd(&s_emit, 1);
+            if (slot < L.cand_cap) out[slot] = record(off, y + 3, v);
+          }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     if (pass == 1) break;
     unsigned need = 0;
     for (int c = 0; c < item.ncells; c++)
       if (s_cnt[c] == 0) need |= 1u << c;
     if (need == 0) break;  // uniform
     cellmask = need;
-    // the cells that get the lower threshold start over: clear their V columns and drop
-    // their corners from the lists
+    // the cells that get the lower threshold start over: clear their V columns (their corners,
+    // all suppressed, are dropped with the lists)
     {
       const int x = tid;
-      if (x < wi && ((need >> (x / wCell)) & 1u))
+      if (x < wi && ((need >> div_small(x, wCellM)) & 1u))
         for (int y = 0; y < hi; y++) s_v[(y + 3) * F_PITCH + x + xoff] = 0;
     }
-    if (!overflow) {
-      int kept = 0;
-      for (int k0 = 0; k0 < ncorner; k0 += 64) {
-        const int k = k0 + lane;
-        const int e = k < ncorner ? (int)s_corner[wave][k] : 0;
-        const bool keep = k < ncorner && !((need >> (((e & 0xFF) - xoff) / wCell)) & 1u);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) s_corner[wave][kept + below(m)] = (uint16_t)e;
-        kept += __popcll(m);
-      }
-      ncorner = kept;
-    }
     __syncthreads();
-  }
-
-  // ---- emit.  Each wavefront reserves room for the corners it has marked with one atomic of
-  // its own and writes them; no workgroup-wide step.  (The order within a level's list is
-  // arbitrary; the quad-tree kernel does not depend on it.)
-  uint32_t* out = cand_all + (size_t)f * P.cand_total + L.cand_off;
-  bool any_overflow = false;
-#pragma unroll
-  for (int w = 0; w < F_THREADS / 64; w++) any_overflow |= s_ncorner[w] < 0;
-  if (!any_overflow) {
-    int nk = 0;
-    for (int k0 = 0; k0 < ncorner; k0 += 64) {
-      const int k = k0 + lane;
-      nk += __popcll(__builtin_amdgcn_ballot_w64(k < ncorner && (s_corner[wave][k] & 0x8000)));
-    }
-    if (nk == 0) return;  // wave-uniform
-    int wbase = 0;
-    if (lane == 0) wbase = atomicAdd(&cand_cnt[f * P.nlevels + item.level], nk);
-    wbase = __builtin_amdgcn_readfirstlane(wbase);
-    for (int k0 = 0; k0 < ncorner; k0 += 64) {
-      const int k = k0 + lane;
-      const int e = k < ncorner ? (int)s_corner[wave][k] : 0;
-      const bool kept = (e & 0x8000) != 0;
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(kept);
-      if (kept) {
-        const int ex = (e & 0xFF) - xoff, ey = (e >> 8) & 0x7F;
-        const int v = s_v[(ey + 3) * F_PITCH + (e & 0xFF)];
-        const int slot = wbase + below(m);
-        const int xr = xb + 3 + ex - kBorder, yr = iniY + 3 + ey - kBorder;
-        if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
-      }
-      wbase += __popcll(m);
-    }
-    return;
-  }
-  // corner lists overflowed: one reservation for the workgroup, dense sweep of the V map
-  if (tid == 0) {
-    int tot = 0;
-    for (int c = 0; c < item.ncells; c++) tot += s_cnt[c];
-    s_total = tot;
-    s_emit = 0;
-    s_base = tot ? atomicAdd(&cand_cnt[f * P.nlevels + item.level], tot) : 0;
-  }
-  __syncthreads();
-  if (s_total == 0) return;
-  const int gbase = s_base;
-  if (tid < wi) {
-    const int x = tid, cj = x / wCell, xc = x - cj * wCell;
-    for (int y = 0; y < hi; y++) {
-      const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + xoff];
-      const int v = q[0];
-      if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) {
-        const int slot = gbase + atomicAdd(&s_emit, 1);
-        const int xr = xb + 3 + x - kBorder, yr = iniY + 3 + y - kBorder;
-        if (slot < L.cand_cap) out[slot] = (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
-      }
-    }
   }
 }
 
