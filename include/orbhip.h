@@ -7,10 +7,16 @@
  * (zhangshaos/ORB_SLAM2, file:line).  Pointers marked "device" are HIP device
  * pointers on the handle's GPU; everything else is host memory.
  *
- * Threading: an extractor handle serves one caller thread at a time (like an
- * ORBextractor instance, which keeps its pyramid between calls); distinct handles
- * are independent.  The matcher entry points keep no state and may be called
- * concurrently.
+ * Threading: an extractor handle serves one caller thread and one stream at a time (like an
+ * ORBextractor instance, which keeps its pyramid between calls): its pyramid, candidate and
+ * keypoint buffers are shared by every call on it, so two calls that overlap (two threads, or
+ * orb_extract_batch_device on two streams without an event between them) race.  Distinct handles
+ * are independent.  The first call of a handle at a new image size, or with more frames than any
+ * call before, allocates and waits for the device; later calls only enqueue.
+ * The host-buffer matcher entry points keep no state and may be called concurrently from several
+ * threads (the reference calls them from its tracking, mapping and loop-closing threads): each
+ * call runs on a stream of its own, waits only for that stream, and never for the null stream or
+ * the whole device.
  */
 #ifndef ORBHIP_H_
 #define ORBHIP_H_

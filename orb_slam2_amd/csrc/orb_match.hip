@@ -7,6 +7,7 @@
 // reference's sequential scan would rank them) and a short ordered phase that
 // replays the reference's query order on those lists, 64 queries per step.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -843,22 +844,107 @@ size_t stereo_lds_bytes(int rows, int max_r, bool desc_in_lds) {
 }
 
 // ---- host helpers -------------------------------------------------------------
+// The host-buffer entry points may be called from several threads at once (the reference calls
+// its matchers from the tracking, mapping and loop-closing threads).  Each call leases a context
+// with a stream of its own and a device arena for its temporaries, so calls neither wait for one
+// another nor for the extractor: nothing here uses the null stream or synchronises the device.
+// Contexts go back to a pool and are reused by whichever thread calls next.
+struct CallCtx {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  unsigned char* arena = nullptr;
+  size_t cap = 0;   // bytes of the arena
+  size_t want = 0;  // bytes the largest call so far needed
+};
+
+class CtxPool {
+ public:
+  CallCtx* acquire(int dev) {
+    CallCtx* c = nullptr;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      auto& fl = free_[dev & 63];
+      if (!fl.empty()) { c = fl.back(); fl.pop_back(); }
+    }
+    if (!c) {
+      c = new CallCtx();
+      c->dev = dev;
+      if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    }
+    if (c->want > c->cap) {  // grow between calls: nothing of this context is in flight
+      if (c->arena) hipFree(c->arena);
+      c->arena = nullptr; c->cap = 0;
+      const size_t n = c->want + c->want / 4 + 4096;
+      if (hipMalloc(reinterpret_cast<void**>(&c->arena), n) == hipSuccess) c->cap = n;
+    }
+    return c;
+  }
+  void release(CallCtx* c) {
+    std::lock_guard<std::mutex> l(m_);
+    free_[c->dev & 63].push_back(c);
+  }
+
+ private:
+  std::mutex m_;
+  std::vector<CallCtx*> free_[64];
+};
+CtxPool g_ctx_pool;
+
+// Device temporaries of one call: bump allocation from the leased arena (blocks that do not fit
+// are allocated on their own and the arena grows before the next call), copies on the call's stream.
 struct DevBuf {
-  std::vector<void*> ptrs;
-  ~DevBuf() { for (void* p : ptrs) hipFree(p); }
+  CallCtx* ctx = nullptr;
+  size_t used = 0, total = 0;
+  std::vector<void*> extra;
+  DevBuf() {
+    int dev = 0;
+    hipGetDevice(&dev);
+    ctx = g_ctx_pool.acquire(dev);
+  }
+  ~DevBuf() {
+    if (!ctx) return;
+    if (!extra.empty()) {
+      hipStreamSynchronize(ctx->stream);
+      for (void* p : extra) hipFree(p);
+    }
+    ctx->want = std::max(ctx->want, total);
+    g_ctx_pool.release(ctx);
+  }
+  hipStream_t stream() const { return ctx ? ctx->stream : nullptr; }
   template <typename T, typename U>
   int up(const T* host, size_t n, U** out) {
     static_assert(sizeof(T) == sizeof(U), "element size mismatch");
     *out = nullptr;
+    if (!ctx) { set_error("could not create a stream"); return ORBHIP_ERR_HIP; }
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
     void* d = nullptr;
-    hipError_t e = hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T));
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
-    ptrs.push_back(d);
+    total += bytes;
+    if (used + bytes <= ctx->cap) {
+      d = ctx->arena + used;
+      used += bytes;
+    } else {
+      hipError_t e = hipMalloc(&d, bytes);
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+      extra.push_back(d);
+    }
     if (host && n) {
-      e = hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice);
-      if (e != hipSuccess) return hip_fail(e, "hipMemcpy H2D");
+      hipError_t e = hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync H2D");
     }
     *out = reinterpret_cast<U*>(d);
+    return ORBHIP_OK;
+  }
+  // results back to the host; valid after sync()
+  template <typename T>
+  int down(T* host, const T* dev, size_t n) {
+    if (!n) return ORBHIP_OK;
+    hipError_t e = hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync D2H");
+    return ORBHIP_OK;
+  }
+  int sync() {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
     return ORBHIP_OK;
   }
 };
@@ -873,6 +959,16 @@ struct DevSel {
   do {                                                \
     int rc__ = (buf).up((host), (size_t)(n), &(out)); \
     if (rc__ != ORBHIP_OK) return rc__;               \
+  } while (0)
+#define DOWN(buf, host, dev, n)                               \
+  do {                                                        \
+    int rc__ = (buf).down((host), (dev), (size_t)(n));        \
+    if (rc__ != ORBHIP_OK) return rc__;                       \
+  } while (0)
+#define SYNC(buf)                       \
+  do {                                  \
+    int rc__ = (buf).sync();            \
+    if (rc__ != ORBHIP_OK) return rc__; \
   } while (0)
 
 constexpr size_t kScratchPerQuery = sizeof(uint2) * MK + sizeof(int) * 3 + sizeof(float4);
@@ -896,13 +992,13 @@ int launch_match(const MatchArgs& A0, int n_pairs, hipStream_t st) {
   A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, A.desc_in_lds != 0, own) <= kLdsLimit;
   const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0, own);
   if (lds > kLdsLimit) { set_error("too many train keypoints for the LDS-resident grid (limit about 9000)"); return ORBHIP_ERR_UNSUPPORTED; }
-  static bool raised[64] = {};  // per device: raise the function's dynamic LDS limit once
+  static std::atomic<bool> raised[64];  // per device: raise the function's dynamic LDS limit once
   int dev = 0;
   ORB_HIP_CHECK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !raised[dev]) {
+  if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
     ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_kernel<MODE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    if (dev >= 0 && dev < 64) raised[dev] = true;
+    if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(match_kernel<MODE>, dim3(n_pairs), dim3(M_THREADS), lds, st, A);
   ORB_HIP_CHECK(hipGetLastError());
@@ -917,10 +1013,7 @@ int run_match(MatchArgs& A, int n_pairs, DevBuf& buf) {
   carve_scratch(A, scratch, nq);
   if (A.ts == 0) A.ts = 1;
   if (A.qs == 0) A.qs = 1;
-  int rc = launch_match<MODE>(A, n_pairs, 0);
-  if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipDeviceSynchronize());
-  return ORBHIP_OK;
+  return launch_match<MODE>(A, n_pairs, buf.stream());  // the caller copies the results back and waits
 }
 
 // Merge-walk of two ordered DBoW2 feature vectors (reference src/ORBmatcher.cc:251-352,
@@ -992,9 +1085,10 @@ int orb_hamming_distance_pairs(int device_id, const uint8_t* a, const uint8_t* b
   UP(buf, a, (size_t)n * 32, da);
   UP(buf, b, (size_t)n * 32, db);
   UP(buf, (const int*)nullptr, n, dout);
-  hipLaunchKernelGGL(hamming_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const uint4*)da, (const uint4*)db, n, dout);
+  hipLaunchKernelGGL(hamming_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, buf.stream(), (const uint4*)da, (const uint4*)db, n, dout);
   ORB_HIP_CHECK(hipGetLastError());
-  ORB_HIP_CHECK(hipMemcpy(out, dout, sizeof(int) * n, hipMemcpyDeviceToHost));
+  DOWN(buf, out, dout, n);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 
@@ -1051,13 +1145,13 @@ int orb_knn2_bruteforce(int device_id, const uint8_t* q, int n_q, const uint8_t*
   UP(buf, (const int*)nullptr, n_q, ds_);
   UP(buf, (const int*)nullptr, n_q, di_);
   UP(buf, (const uint8_t*)nullptr, n_q, dacc);
-  int rc = orb_knn2_device(device_id, dq, n_q, ddb, n_db, 0, ratio, db_, ds_, di_, dacc, nullptr);
+  int rc = orb_knn2_device(device_id, dq, n_q, ddb, n_db, 0, ratio, db_, ds_, di_, dacc, buf.stream());
   if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipDeviceSynchronize());
-  ORB_HIP_CHECK(hipMemcpy(best, db_, sizeof(int) * n_q, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(second, ds_, sizeof(int) * n_q, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(idx, di_, sizeof(int) * n_q, hipMemcpyDeviceToHost));
-  if (accept) ORB_HIP_CHECK(hipMemcpy(accept, dacc, n_q, hipMemcpyDeviceToHost));
+  DOWN(buf, best, db_, n_q);
+  DOWN(buf, second, ds_, n_q);
+  DOWN(buf, idx, di_, n_q);
+  if (accept) DOWN(buf, accept, dacc, n_q);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 
@@ -1090,8 +1184,9 @@ int orb_search_by_projection_frames(int device_id, int n_pairs, int max_last, in
   UP(buf, (const int*)nullptr, nt, A.out_match); UP(buf, (const int*)nullptr, n_pairs, A.n_matches);
   int rc = run_match<MODE_FRAMES>(A, n_pairs, buf);
   if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipMemcpy(cur_match, A.out_match, sizeof(int) * nt, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int) * n_pairs, hipMemcpyDeviceToHost));
+  DOWN(buf, cur_match, A.out_match, nt);
+  DOWN(buf, n_matches, A.n_matches, n_pairs);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 
@@ -1212,8 +1307,9 @@ int orb_search_by_projection_mappoints(int device_id, OrbFrameBounds bounds, con
   UP(buf, (const int*)nullptr, n_f, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
   int rc = run_match<MODE_MAPPOINTS>(A, 1, buf);
   if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipMemcpy(f_match, A.out_match, sizeof(int) * n_f, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  DOWN(buf, f_match, A.out_match, n_f);
+  DOWN(buf, n_matches, A.n_matches, 1);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 
@@ -1246,8 +1342,9 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
   UP(buf, (const int*)nullptr, n_t, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
   int rc = run_match<MODE_WINDOW>(A, 1, buf);
   if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipMemcpy(t_match, A.out_match, sizeof(int) * n_t, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  DOWN(buf, t_match, A.out_match, n_t);
+  DOWN(buf, n_matches, A.n_matches, 1);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 
@@ -1288,8 +1385,9 @@ int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* 
   UP(buf, (const int*)nullptr, 1, A.n_matches);
   int rc = run_match<MODE_BEST>(A, 1, buf);
   if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipMemcpy(best_idx, A.out_match, sizeof(int) * n_q, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(best_dist, A.out_dist, sizeof(int) * n_q, hipMemcpyDeviceToHost));
+  DOWN(buf, best_idx, A.out_match, n_q);
+  DOWN(buf, best_dist, A.out_dist, n_q);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 
@@ -1327,8 +1425,9 @@ int orb_search_for_initialization(int device_id, OrbFrameBounds bounds, int n1, 
   UP(buf, (const int*)nullptr, n1, A.out_match); UP(buf, (const int*)nullptr, 1, A.n_matches);
   int rc = run_match<MODE_INIT>(A, 1, buf);
   if (rc != ORBHIP_OK) return rc;
-  ORB_HIP_CHECK(hipMemcpy(matches12, A.out_match, sizeof(int) * n1, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  DOWN(buf, matches12, A.out_match, n1);
+  DOWN(buf, n_matches, A.n_matches, 1);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 
@@ -1387,9 +1486,10 @@ int orb_search_for_triangulation(int device_id, int n1, const float* x1, const f
   int rc = run_match<MODE_TRIANG>(A, 1, buf);
   if (rc != ORBHIP_OK) return rc;
   std::vector<int> m(max_q);
-  ORB_HIP_CHECK(hipMemcpy(m.data(), A.out_match, sizeof(int) * max_q, hipMemcpyDeviceToHost));
+  DOWN(buf, m.data(), A.out_match, max_q);
+  DOWN(buf, n_matches, A.n_matches, 1);
+  SYNC(buf);
   std::copy(m.begin(), m.begin() + n1, matches12);
-  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
   return ORBHIP_OK;
 }
 
@@ -1444,9 +1544,10 @@ int orb_search_by_bow(int device_id, int n1, const float* angle1, const uint8_t*
   int rc = run_match<MODE_BOW>(A, 1, buf);
   if (rc != ORBHIP_OK) return rc;
   std::vector<int> m(max_q);
-  ORB_HIP_CHECK(hipMemcpy(m.data(), A.out_match, sizeof(int) * max_q, hipMemcpyDeviceToHost));
+  DOWN(buf, m.data(), A.out_match, max_q);
+  DOWN(buf, n_matches, A.n_matches, 1);
+  SYNC(buf);
   std::copy(m.begin(), m.begin() + n1, matches12);
-  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
   return ORBHIP_OK;
 }
 
@@ -1487,12 +1588,12 @@ int orb_stereo_match(int device_id, int rows, int n_left, const float* l_x, cons
   UP(buf, (const int*)nullptr, 1, A.n_matches);
   ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stereo_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-  hipLaunchKernelGGL(stereo_kernel, dim3(1), dim3(M_THREADS), lds, 0, A);
+  hipLaunchKernelGGL(stereo_kernel, dim3(1), dim3(M_THREADS), lds, buf.stream(), A);
   ORB_HIP_CHECK(hipGetLastError());
-  ORB_HIP_CHECK(hipDeviceSynchronize());
-  ORB_HIP_CHECK(hipMemcpy(best_idx, A.best_idx, sizeof(int) * n_left, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(best_dist, A.best_dist, sizeof(int) * n_left, hipMemcpyDeviceToHost));
-  ORB_HIP_CHECK(hipMemcpy(n_matches, A.n_matches, sizeof(int), hipMemcpyDeviceToHost));
+  DOWN(buf, best_idx, A.best_idx, n_left);
+  DOWN(buf, best_dist, A.best_dist, n_left);
+  DOWN(buf, n_matches, A.n_matches, 1);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 

@@ -73,3 +73,40 @@ def projection_scene(rng, n_last, n_cur, rows, cols, frac_mp=0.8, conflict_clust
     last = dict(mp_obs=obs, xw=Xw, mp_desc=ldesc, octave=loct, angle=lang)
     cur = dict(x=cx_, y=cy_, octave=coct, angle=cang, desc=cdesc, obs=cobs)
     return dict(Tcw=Tcw, K=(fx, fy, cx, cy), bounds=(0.0, float(cols), 0.0, float(rows)), sf=sf, last=last, cur=cur)
+
+
+def triangulation_scene(rng, n1, n2, rows=480, cols=752, nnodes=60):
+    """Two keyframes related by a pure x-translation (epipolar lines are image rows) with feature
+    vectors over `nnodes` vocabulary nodes.  Returns the flat arrays the oracle takes and the
+    pieces the KeyFrame mirror is built from."""
+    sf, s2 = scale_tables()
+    x2, y2, o2, a2, d2 = random_frame_arrays(rng, n2, rows, cols)
+    src = rng.integers(0, n2, n1)
+    x1 = (x2[src] + rng.uniform(5, 60, n1)).astype(np.float32)
+    y1 = (y2[src] + rng.normal(0, 0.7, n1)).astype(np.float32)
+    o1 = o2[src].copy()
+    a1 = ((a2[src] + rng.normal(0, 6, n1)) % 360).astype(np.float32)
+    d1 = flip_bits(rng, d2[src], 45)
+    K = (np.float32(500), np.float32(500), np.float32(376), np.float32(240))
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) * np.float32(0.002)
+    node_of2 = rng.integers(0, nnodes, n2)
+    node_of1 = np.where(rng.uniform(0, 1, n1) < 0.8, node_of2[src], rng.integers(0, nnodes + 5, n1))
+    fv1 = {int(k) * 3: [int(i) for i in np.nonzero(node_of1 == k)[0]] for k in np.unique(node_of1)}
+    fv2 = {int(k) * 3: [int(i) for i in np.nonzero(node_of2 == k)[0]] for k in np.unique(node_of2)}
+    has1 = rng.uniform(0, 1, n1) < 0.3
+    has2 = rng.uniform(0, 1, n2) < 0.3
+    T1 = np.eye(4, dtype=np.float32)
+    T2 = np.eye(4, dtype=np.float32); T2[0, 3] = 0.5; T2[2, 3] = 0.3
+    return dict(sf=sf, s2=s2, K=K, F12=F12, bounds=(0, cols, 0, rows), T1=T1, T2=T2, fv1=fv1, fv2=fv2,
+                k1=dict(x=x1, y=y1, octave=o1, angle=a1, desc=d1, has_mp=has1.astype(np.uint8)),
+                k2=dict(x=x2, y=y2, octave=o2, angle=a2, desc=d2, has_mp=has2.astype(np.uint8)))
+
+
+def flat_feature_vector(fv):
+    """{node: [feature indices]} (ordered) -> sorted node ids + CSR item lists."""
+    nodes = np.array(list(fv.keys()), np.int32)
+    start, items = [0], []
+    for v in fv.values():
+        items.extend(v)
+        start.append(len(items))
+    return dict(node=nodes, start=np.array(start, np.int32), items=np.array(items, np.int32))
