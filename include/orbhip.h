@@ -274,6 +274,21 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
                        const float* q_angle, const uint8_t* q_desc, int max_dist,
                        int check_orientation, int* t_match, int* n_matches);
 
+/* orb_match_windowed with the keypoints held by a KeyFrame instead of a Frame.
+ * KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:732-776) walks the grid that the Frame built with
+ * its float bounds (src/KeyFrame.cc:45-60), but subtracts the KeyFrame's own mnMinX / mnMinY,
+ * which are const int (include/KeyFrame.h:411-414, truncated from the Frame's floats at
+ * src/KeyFrame.cc:70): with a distorted camera the cell range of a window can differ at cell
+ * edges.  This is what the loop-closing overload SearchByProjection(KeyFrame*, Scw, ...)
+ * (src/ORBmatcher.cc:470) sees; `bounds` are the Frame's float bounds as everywhere else. */
+int orb_match_windowed_keyframe(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x,
+                                const float* t_y, const int* t_octave, const float* t_angle,
+                                const uint8_t* t_desc, const uint8_t* t_taken, int n_q,
+                                const uint8_t* q_active, const float* q_u, const float* q_v,
+                                const float* q_radius, const int* q_min_level, const int* q_max_level,
+                                const float* q_angle, const uint8_t* q_desc, int max_dist,
+                                int check_orientation, int* t_match, int* n_matches);
+
 /* ORBmatcher::SearchForInitialization(const Frame& F1, const Frame& F2,
  * vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize)
  * (src/ORBmatcher.cc:543-686).  Per F1 feature of octave 0: the level-0 features of F2
@@ -305,6 +320,16 @@ int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* 
                     const uint8_t* q_active, const float* q_u, const float* q_v,
                     const float* q_radius, const int* q_level, const uint8_t* q_desc,
                     int* best_idx, int* best_dist);
+
+/* orb_window_best on a KeyFrame's grid (int-truncated query origin, see
+ * orb_match_windowed_keyframe): every caller in the reference - Fuse x2 (src/ORBmatcher.cc:1133,
+ * :1302) and SearchBySim3 (:1479, :1560) - queries a KeyFrame. */
+int orb_window_best_keyframe(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x,
+                             const float* t_y, const int* t_octave, const uint8_t* t_desc,
+                             const float* inv_level_sigma2, int nlevels, double chi2, int n_q,
+                             const uint8_t* q_active, const float* q_u, const float* q_v,
+                             const float* q_radius, const int* q_level, const uint8_t* q_desc,
+                             int* best_idx, int* best_dist);
 
 /* ORBmatcher::SearchByBoW, both overloads:
  *   SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches)

@@ -250,15 +250,17 @@ def search_by_projection_mappoints(bounds, scale_factors, frame, mps, th, nnrati
     return n, match[:len(f_x)].copy()
 
 
-def match_windowed(bounds, train, queries, max_dist, check_ori):
-    """train: dict(x, y, octave, angle, desc, taken); queries: dict(active, u, v, r, minl, maxl, angle, desc)."""
+def match_windowed(bounds, train, queries, max_dist, check_ori, keyframe=False):
+    """train: dict(x, y, octave, angle, desc, taken); queries: dict(active, u, v, r, minl, maxl, angle, desc).
+    keyframe: the train side is a KeyFrame (queries subtract its int-truncated mnMinX / mnMinY)."""
     t_x, t_y, t_o, t_a = _f32(train["x"]), _f32(train["y"]), _i32(train["octave"]), _f32(train["angle"])
     t_d, t_t = _u8(train["desc"]), _u8(train["taken"])
     q_a, q_u, q_v, q_r = _u8(queries["active"]), _f32(queries["u"]), _f32(queries["v"]), _f32(queries["r"])
     q_lo, q_hi, q_ang, q_d = _i32(queries["minl"]), _i32(queries["maxl"]), _f32(queries["angle"]), _u8(queries["desc"])
     match = np.empty(max(len(t_x), 1), np.int32)
     f = C.c_float
-    n = lib().orc_match_windowed(f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]),
+    fn = lib().orc_match_windowed_keyframe if keyframe else lib().orc_match_windowed
+    n = fn(f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]),
                                  len(t_x), _p(t_x), _p(t_y), _p(t_o), _p(t_a), _p(t_d), _p(t_t),
                                  len(q_a), _p(q_a), _p(q_u), _p(q_v), _p(q_r), _p(q_lo), _p(q_hi), _p(q_ang), _p(q_d),
                                  int(max_dist), int(check_ori), _p(match))
@@ -282,8 +284,9 @@ def search_for_initialization(bounds, f1, prev, f2, window, nnratio, check_ori=T
     return n, m12[:n1].copy()
 
 
-def window_best(bounds, train, queries, inv_level_sigma2=None, chi2=0.0):
+def window_best(bounds, train, queries, inv_level_sigma2=None, chi2=0.0, keyframe=False):
     """train: dict(x, y, octave, desc); queries: dict(active, u, v, r, level, desc).
+    keyframe: the train side is a KeyFrame (queries subtract its int-truncated mnMinX / mnMinY).
     Returns (best_idx, best_dist); no candidate -> (-1, INT_MAX)."""
     t_x, t_y, t_o, t_d = _f32(train["x"]), _f32(train["y"]), _i32(train["octave"]), _u8(train["desc"])
     q_a, q_u, q_v, q_r = _u8(queries["active"]), _f32(queries["u"]), _f32(queries["v"]), _f32(queries["r"])
@@ -293,8 +296,9 @@ def window_best(bounds, train, queries, inv_level_sigma2=None, chi2=0.0):
     inv = _f32(inv_level_sigma2) if inv_level_sigma2 is not None else np.ones(16, np.float32)
     f = C.c_float
     L = lib()
-    L.orc_window_best.restype = None
-    L.orc_window_best(f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]), C.c_int(len(t_x)), _p(t_x), _p(t_y), _p(t_o),
+    fn = L.orc_window_best_keyframe if keyframe else L.orc_window_best
+    fn.restype = None
+    fn(f(bounds[0]), f(bounds[1]), f(bounds[2]), f(bounds[3]), C.c_int(len(t_x)), _p(t_x), _p(t_y), _p(t_o),
                       _p(t_d), _p(inv), C.c_double(chi2), C.c_int(nq), _p(q_a), _p(q_u), _p(q_v), _p(q_r), _p(q_l), _p(q_d),
                       _p(bi), _p(bd))
     return bi[:nq].copy(), bd[:nq].copy()

@@ -746,6 +746,7 @@ ORC_API void orc_three_maxima(const int* sizes, int L, int* ind1, int* ind2, int
  * The grid is returned as CSR over cells in [ix][iy] order (ix major). */
 typedef struct {
   float minX, maxX, minY, maxY, invW, invH;
+  float qminX, qminY; /* origin the queries subtract: the Frame's float bounds, or a KeyFrame's int ones */
   int n;
   const float* kx; const float* ky; const int* koct;
   int* start; /* GRID_COLS*GRID_ROWS + 1 */
@@ -755,6 +756,7 @@ typedef struct {
 static void grid_build(OrcGrid* g, int n, const float* kx, const float* ky, const int* koct,
                        float minX, float maxX, float minY, float maxY) {
   g->minX = minX; g->maxX = maxX; g->minY = minY; g->maxY = maxY;
+  g->qminX = minX; g->qminY = minY;
   g->invW = (float)GRID_COLS / (float)(maxX - minX);
   g->invH = (float)GRID_ROWS / (float)(maxY - minY);
   g->n = n; g->kx = kx; g->ky = ky; g->koct = koct;
@@ -773,17 +775,22 @@ static void grid_build(OrcGrid* g, int n, const float* kx, const float* ky, cons
   free(fill); free(cell);
 }
 static void grid_free(OrcGrid* g) { free(g->start); free(g->items); }
+/* KeyFrame::GetFeaturesInArea (KeyFrame.cc:732-776) runs on the grid the Frame built with its
+ * float bounds and cell sizes (KeyFrame.cc:45,53-60), but subtracts the KeyFrame's own mnMinX /
+ * mnMinY, which are const int (KeyFrame.h:411-414; initialised from the Frame's floats,
+ * KeyFrame.cc:70, i.e. truncated towards zero). */
+static void grid_use_keyframe_origin(OrcGrid* g) { g->qminX = (float)(int)g->minX; g->qminY = (float)(int)g->minY; }
 
-/* GetFeaturesInArea (Frame.cc:371-449) */
+/* GetFeaturesInArea (Frame.cc:371-449; KeyFrame.cc:732-776 with the KeyFrame's origin and no level range) */
 static int grid_query(const OrcGrid* g, float x, float y, float r, int minLevel, int maxLevel, int* out) {
   int n = 0;
-  int nMinCellX = (int)floorf((x - g->minX - r) * g->invW); if (nMinCellX < 0) nMinCellX = 0;
+  int nMinCellX = (int)floorf((x - g->qminX - r) * g->invW); if (nMinCellX < 0) nMinCellX = 0;
   if (nMinCellX >= GRID_COLS) return 0;
-  int nMaxCellX = (int)ceilf((x - g->minX + r) * g->invW); if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+  int nMaxCellX = (int)ceilf((x - g->qminX + r) * g->invW); if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
   if (nMaxCellX < 0) return 0;
-  int nMinCellY = (int)floorf((y - g->minY - r) * g->invH); if (nMinCellY < 0) nMinCellY = 0;
+  int nMinCellY = (int)floorf((y - g->qminY - r) * g->invH); if (nMinCellY < 0) nMinCellY = 0;
   if (nMinCellY >= GRID_ROWS) return 0;
-  int nMaxCellY = (int)ceilf((y - g->minY + r) * g->invH); if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+  int nMaxCellY = (int)ceilf((y - g->qminY + r) * g->invH); if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
   if (nMaxCellY < 0) return 0;
   const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
   for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
@@ -949,8 +956,8 @@ ORC_API int orc_search_by_projection_mappoints(
  * (:470-520): per active query, GetFeaturesInArea with a level range, skip keypoints that
  * hold a map point, strict '<' best, accept if best <= max_dist and take the keypoint;
  * optional rotation histogram (:1880-1926). */
-ORC_API int orc_match_windowed(
-    float minX, float maxX, float minY, float maxY,
+static int match_windowed_impl(
+    int keyframe, float minX, float maxX, float minY, float maxY,
     int nt, const float* t_x, const float* t_y, const int* t_oct, const float* t_angle, const uint8_t* t_desc,
     const uint8_t* t_taken,
     int nq, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_r, const int* q_minl,
@@ -958,6 +965,7 @@ ORC_API int orc_match_windowed(
   int nmatches = 0;
   OrcGrid g;
   grid_build(&g, nt, t_x, t_y, t_oct, minX, maxX, minY, maxY);
+  if (keyframe) grid_use_keyframe_origin(&g);
   int* cand = (int*)malloc(sizeof(int) * (nt + 1));
   uint8_t* taken = (uint8_t*)malloc(nt + 1);
   int* hist_items = (int*)malloc(sizeof(int) * (size_t)(nq + 1));
@@ -1121,12 +1129,13 @@ ORC_API int orc_search_for_initialization(float minX, float maxX, float minY, fl
  * reprojection gate e2 * mvInvLevelSigma2[kpLevel] > 5.99 -> skip (:1158-1164; chi2 > 0
  * turns it on), and the first minimum of the descriptor distance.  Queries are independent.
  * best_idx[i] = -1 / best_dist[i] = INT_MAX when no candidate is left. */
-ORC_API void orc_window_best(float minX, float maxX, float minY, float maxY, int nt, const float* t_x, const float* t_y,
-                             const int* t_oct, const uint8_t* t_desc, const float* inv_level_sigma2, double chi2, int nq,
-                             const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_r,
-                             const int* q_level, const uint8_t* q_desc, int* best_idx, int* best_dist) {
+static void window_best_impl(int keyframe, float minX, float maxX, float minY, float maxY, int nt, const float* t_x,
+                             const float* t_y, const int* t_oct, const uint8_t* t_desc, const float* inv_level_sigma2,
+                             double chi2, int nq, const uint8_t* q_active, const float* q_u, const float* q_v,
+                             const float* q_r, const int* q_level, const uint8_t* q_desc, int* best_idx, int* best_dist) {
   OrcGrid g;
   grid_build(&g, nt, t_x, t_y, t_oct, minX, maxX, minY, maxY);
+  if (keyframe) grid_use_keyframe_origin(&g);
   int* cand = (int*)malloc(sizeof(int) * (nt + 1));
   for (int i = 0; i < nq; i++) {
     best_idx[i] = -1; best_dist[i] = 0x7FFFFFFF;
@@ -1459,4 +1468,39 @@ ORC_API void orc_undistort_points(int n, const float* xy, const float* K4 /* fx 
     out[2 * i] = (float)(xx * ww);
     out[2 * i + 1] = (float)(yy * ww);
   }
+}
+
+/* The two scans above on a Frame's grid (float origin) and on a KeyFrame's (int origin). */
+ORC_API int orc_match_windowed(
+    float minX, float maxX, float minY, float maxY,
+    int nt, const float* t_x, const float* t_y, const int* t_oct, const float* t_angle, const uint8_t* t_desc,
+    const uint8_t* t_taken,
+    int nq, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_r, const int* q_minl,
+    const int* q_maxl, const float* q_angle, const uint8_t* q_desc, int max_dist, int check_ori, int* t_match) {
+  return match_windowed_impl(0, minX, maxX, minY, maxY, nt, t_x, t_y, t_oct, t_angle, t_desc, t_taken, nq, q_active, q_u,
+                             q_v, q_r, q_minl, q_maxl, q_angle, q_desc, max_dist, check_ori, t_match);
+}
+ORC_API int orc_match_windowed_keyframe(
+    float minX, float maxX, float minY, float maxY,
+    int nt, const float* t_x, const float* t_y, const int* t_oct, const float* t_angle, const uint8_t* t_desc,
+    const uint8_t* t_taken,
+    int nq, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_r, const int* q_minl,
+    const int* q_maxl, const float* q_angle, const uint8_t* q_desc, int max_dist, int check_ori, int* t_match) {
+  return match_windowed_impl(1, minX, maxX, minY, maxY, nt, t_x, t_y, t_oct, t_angle, t_desc, t_taken, nq, q_active, q_u,
+                             q_v, q_r, q_minl, q_maxl, q_angle, q_desc, max_dist, check_ori, t_match);
+}
+ORC_API void orc_window_best(float minX, float maxX, float minY, float maxY, int nt, const float* t_x, const float* t_y,
+                             const int* t_oct, const uint8_t* t_desc, const float* inv_level_sigma2, double chi2, int nq,
+                             const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_r,
+                             const int* q_level, const uint8_t* q_desc, int* best_idx, int* best_dist) {
+  window_best_impl(0, minX, maxX, minY, maxY, nt, t_x, t_y, t_oct, t_desc, inv_level_sigma2, chi2, nq, q_active, q_u, q_v,
+                   q_r, q_level, q_desc, best_idx, best_dist);
+}
+ORC_API void orc_window_best_keyframe(float minX, float maxX, float minY, float maxY, int nt, const float* t_x,
+                                      const float* t_y, const int* t_oct, const uint8_t* t_desc,
+                                      const float* inv_level_sigma2, double chi2, int nq, const uint8_t* q_active,
+                                      const float* q_u, const float* q_v, const float* q_r, const int* q_level,
+                                      const uint8_t* q_desc, int* best_idx, int* best_dist) {
+  window_best_impl(1, minX, maxX, minY, maxY, nt, t_x, t_y, t_oct, t_desc, inv_level_sigma2, chi2, nq, q_active, q_u, q_v,
+                   q_r, q_level, q_desc, best_idx, best_dist);
 }

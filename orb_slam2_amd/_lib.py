@@ -36,7 +36,7 @@ EXPORTS = [
     "orb_extractor_get_scale_tables", "orb_extractor_get_level_quotas", "orb_extractor_max_keypoints",
     "orb_extract", "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync",
     "orb_extractor_set_profiling", "orb_extractor_set_input_format", "orb_extractor_stage_times", "orb_match_scratch_bytes",
-    "orb_search_by_projection_frames_device", "orb_search_by_projection_frames_noalloc", "orb_match_windowed", "orb_stereo_match", "orb_search_by_bow", "orb_window_best", "orb_search_for_initialization",
+    "orb_search_by_projection_frames_device", "orb_search_by_projection_frames_noalloc", "orb_match_windowed", "orb_match_windowed_keyframe", "orb_window_best_keyframe", "orb_stereo_match", "orb_search_by_bow", "orb_window_best", "orb_search_for_initialization",
     "orb_get_pyramid_level", "orb_get_blurred_level", "orb_get_fast_candidates", "orb_get_level_keypoints",
     "orb_hamming_distance_pairs", "orb_search_by_projection_frames", "orb_search_by_projection_mappoints",
     "orb_search_for_triangulation", "orb_knn2_device", "orb_knn2_device_algo", "orb_knn2_merge_device", "orb_knn2_bruteforce",
@@ -91,8 +91,10 @@ def lib():
     L.orb_search_by_projection_mappoints.argtypes = (
         [i, FrameBounds, vp, i, i] + [vp] * 5 + [i] + [vp] * 7 + [f, f, vp, vp])
     L.orb_match_windowed.argtypes = [i, FrameBounds, i] + [vp] * 6 + [i] + [vp] * 8 + [i, i, vp, vp]
+    L.orb_match_windowed_keyframe.argtypes = L.orb_match_windowed.argtypes
     L.orb_search_for_initialization.argtypes = [i, FrameBounds, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, f, f, i, vp, vp]
     L.orb_window_best.argtypes = [i, FrameBounds, i, vp, vp, vp, vp, vp, i, C.c_double, i, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orb_window_best_keyframe.argtypes = L.orb_window_best.argtypes
     L.orb_search_by_bow.argtypes = [i, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, f, i, i, vp, vp]
     L.orb_stereo_match.argtypes = [i, i, i] + [vp] * 4 + [i] + [vp] * 5 + [i, f, f, i, vp, vp, vp]
     L.orb_search_for_triangulation.argtypes = (

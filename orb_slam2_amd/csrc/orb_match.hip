@@ -178,6 +178,7 @@ constexpr bool mode_out_by_query(int mode) { return mode_bucketed(mode) || mode 
 
 struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
+  int keyframe_origin;  // window queries subtract the int-truncated origin (KeyFrame::GetFeaturesInArea)
   int lists_in_lds;  // the ranked candidate lists of all queries fit in LDS next to the grid
   int desc_in_lds;   // the train descriptors are staged in LDS (chosen before the lists)
   int ts, qs;  // element stride (4-byte units) of t_x/t_y/t_oct/t_angle and of q_oct/q_angle:
@@ -197,6 +198,7 @@ struct MatchArgs {
   const float* tcw;
   float fx, fy, cx, cy;
   OrbFrameBounds b;
+  float q_min_x, q_min_y;  // origin the window queries subtract: b.min_x / b.min_y for a Frame, truncated to int for a KeyFrame
   float sf[kMaxLevels];
   float sigma2[kMaxLevels];
   float f12[9];
@@ -276,13 +278,13 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
     const int minLevel = (lv & 0xFFFF) - 1024, maxLevel = (lv >> 16) - 1024;
     const float invW = (float)GRID_COLS / (A.b.max_x - A.b.min_x);
     const float invH = (float)GRID_ROWS / (A.b.max_y - A.b.min_y);
-    const int nMinCellX = max(0, (int)floorf((x - A.b.min_x - r) * invW));
+    const int nMinCellX = max(0, (int)floorf((x - A.q_min_x - r) * invW));
     if (nMinCellX >= GRID_COLS) return;
-    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - A.b.min_x + r) * invW));
+    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - A.q_min_x + r) * invW));
     if (nMaxCellX < 0) return;
-    const int nMinCellY = max(0, (int)floorf((y - A.b.min_y - r) * invH));
+    const int nMinCellY = max(0, (int)floorf((y - A.q_min_y - r) * invH));
     if (nMinCellY >= GRID_ROWS) return;
-    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - A.b.min_y + r) * invH));
+    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - A.q_min_y + r) * invH));
     if (nMaxCellY < 0) return;
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     int pos = 0;
@@ -985,6 +987,8 @@ void carve_scratch(MatchArgs& A, void* scratch, size_t nq) {
 template <int MODE>
 int launch_match(const MatchArgs& A0, int n_pairs, hipStream_t st) {
   MatchArgs A = A0;
+  if (!A.keyframe_origin) { A.q_min_x = A.b.min_x; A.q_min_y = A.b.min_y; }
+  else { A.q_min_x = (float)(int)A.b.min_x; A.q_min_y = (float)(int)A.b.min_y; }  // KeyFrame::mnMinX / mnMinY are const int
   constexpr size_t kLdsLimit = 156 * 1024;
   // descriptors first (every candidate reads them), then the ranked lists if there is room
   constexpr bool own = MODE == MODE_INIT;
@@ -1313,7 +1317,7 @@ int orb_search_by_projection_mappoints(int device_id, OrbFrameBounds bounds, con
   return ORBHIP_OK;
 }
 
-int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
+static int match_windowed_impl(int keyframe, int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
                        const int* t_octave, const float* t_angle, const uint8_t* t_desc, const uint8_t* t_taken,
                        int n_q, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_radius,
                        const int* q_min_level, const int* q_max_level, const float* q_angle, const uint8_t* q_desc,
@@ -1330,6 +1334,7 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
   DevBuf buf;
   MatchArgs A{};
   A.max_q = n_q; A.max_t = n_t; A.nlevels = 1; A.check_ori = check_orientation; A.b = bounds; A.max_dist = max_dist;
+  A.keyframe_origin = keyframe;
   std::vector<int> taken(n_t);
   for (int i = 0; i < n_t; i++) taken[i] = t_taken[i] ? 1 : -1;
   UP(buf, &n_q, 1, A.n_q); UP(buf, &n_t, 1, A.n_t);
@@ -1348,7 +1353,28 @@ int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const floa
   return ORBHIP_OK;
 }
 
-int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
+int orb_match_windowed(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
+                       const int* t_octave, const float* t_angle, const uint8_t* t_desc, const uint8_t* t_taken,
+                       int n_q, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_radius,
+                       const int* q_min_level, const int* q_max_level, const float* q_angle, const uint8_t* q_desc,
+                       int max_dist, int check_orientation, int* t_match, int* n_matches) {
+  return match_windowed_impl(0, device_id, bounds, n_t, t_x, t_y, t_octave, t_angle, t_desc, t_taken, n_q, q_active, q_u, q_v,
+                             q_radius, q_min_level, q_max_level, q_angle, q_desc, max_dist, check_orientation, t_match,
+                             n_matches);
+}
+
+int orb_match_windowed_keyframe(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
+                                const int* t_octave, const float* t_angle, const uint8_t* t_desc,
+                                const uint8_t* t_taken, int n_q, const uint8_t* q_active, const float* q_u,
+                                const float* q_v, const float* q_radius, const int* q_min_level,
+                                const int* q_max_level, const float* q_angle, const uint8_t* q_desc, int max_dist,
+                                int check_orientation, int* t_match, int* n_matches) {
+  return match_windowed_impl(1, device_id, bounds, n_t, t_x, t_y, t_octave, t_angle, t_desc, t_taken, n_q, q_active, q_u, q_v,
+                             q_radius, q_min_level, q_max_level, q_angle, q_desc, max_dist, check_orientation, t_match,
+                             n_matches);
+}
+
+static int window_best_impl(int keyframe, int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
                     const int* t_octave, const uint8_t* t_desc, const float* inv_level_sigma2, int nlevels, double chi2,
                     int n_q, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_radius,
                     const int* q_level, const uint8_t* q_desc, int* best_idx, int* best_dist) {
@@ -1365,6 +1391,7 @@ int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* 
   DevBuf buf;
   MatchArgs A{};
   A.max_q = n_q; A.max_t = n_t; A.nlevels = 1; A.b = bounds; A.chi2 = chi2 > 0 ? chi2 : 0.0;
+  A.keyframe_origin = keyframe;
   if (chi2 > 0) {
     for (int i = 0; i < kMaxLevels; i++) A.sigma2[i] = inv_level_sigma2[std::min(i, nlevels - 1)];
     for (int i = 0; i < n_t; i++)
@@ -1389,6 +1416,23 @@ int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* 
   DOWN(buf, best_dist, A.out_dist, n_q);
   SYNC(buf);
   return ORBHIP_OK;
+}
+
+int orb_window_best(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
+                    const int* t_octave, const uint8_t* t_desc, const float* inv_level_sigma2, int nlevels, double chi2,
+                    int n_q, const uint8_t* q_active, const float* q_u, const float* q_v, const float* q_radius,
+                    const int* q_level, const uint8_t* q_desc, int* best_idx, int* best_dist) {
+  return window_best_impl(0, device_id, bounds, n_t, t_x, t_y, t_octave, t_desc, inv_level_sigma2, nlevels, chi2, n_q,
+                          q_active, q_u, q_v, q_radius, q_level, q_desc, best_idx, best_dist);
+}
+
+int orb_window_best_keyframe(int device_id, OrbFrameBounds bounds, int n_t, const float* t_x, const float* t_y,
+                             const int* t_octave, const uint8_t* t_desc, const float* inv_level_sigma2, int nlevels,
+                             double chi2, int n_q, const uint8_t* q_active, const float* q_u, const float* q_v,
+                             const float* q_radius, const int* q_level, const uint8_t* q_desc, int* best_idx,
+                             int* best_dist) {
+  return window_best_impl(1, device_id, bounds, n_t, t_x, t_y, t_octave, t_desc, inv_level_sigma2, nlevels, chi2, n_q,
+                          q_active, q_u, q_v, q_radius, q_level, q_desc, best_idx, best_dist);
 }
 
 int orb_search_for_initialization(int device_id, OrbFrameBounds bounds, int n1, const int* octave1, const float* angle1,

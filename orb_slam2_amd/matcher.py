@@ -78,7 +78,11 @@ class ORBmatcher:
         match = np.full(max(F.N, 1), -1, np.int32)
         nm = C.c_int(0)
         b = FrameBounds(F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY)
-        check(self._lib.orb_match_windowed(
+        # a KeyFrame answers GetFeaturesInArea with its int-truncated origin (reference
+        # include/KeyFrame.h:411-414, src/KeyFrame.cc:732-776), a Frame with the float one
+        from .frame import KeyFrame
+        fn = self._lib.orb_match_windowed_keyframe if isinstance(F, KeyFrame) else self._lib.orb_match_windowed
+        check(fn(
             self.device, b, F.N, ptr(_f32(k["x"])), ptr(_f32(k["y"])), ptr(_i32(k["octave"])), ptr(_f32(k["angle"])),
             ptr(F.mDescriptors), ptr(_u8(taken)), nq, ptr(_u8(q["active"])), ptr(_f32(q["u"])), ptr(_f32(q["v"])),
             ptr(_f32(q["r"])), ptr(_i32(q["minl"])), ptr(_i32(q["maxl"])), ptr(_f32(q["angle"])), ptr(_u8(q["desc"])),
@@ -324,7 +328,7 @@ class ORBmatcher:
         bd = np.zeros(max(nq, 1), np.int32)
         inv = _f32(inv_sigma2) if inv_sigma2 is not None else np.ones(1, np.float32)
         b = FrameBounds(KF.mnMinX, KF.mnMaxX, KF.mnMinY, KF.mnMaxY)
-        check(self._lib.orb_window_best(
+        check(self._lib.orb_window_best_keyframe(  # every caller queries a KeyFrame (src/KeyFrame.cc:732-776)
             self.device, b, KF.N, ptr(_f32(k["x"])), ptr(_f32(k["y"])), ptr(_i32(k["octave"])), ptr(KF.mDescriptors),
             ptr(inv), len(inv), float(chi2), nq, ptr(_u8(q["active"])), ptr(_f32(q["u"])), ptr(_f32(q["v"])),
             ptr(_f32(q["r"])), ptr(_i32(q["minl"])), ptr(_u8(q["desc"])), ptr(bi), ptr(bd)))

@@ -783,3 +783,50 @@ def test_knn2_full_size_properties(oracle):
                                        C.c_void_p(macc.data_ptr()), None))
     torch.cuda.synchronize()
     assert torch.equal(out, full) and torch.equal(macc, facc)
+
+
+@pytest.mark.parametrize("bounds", [(-3.7, 755.2, -2.4, 482.9), (3.6, 748.9, 2.7, 477.2)])
+def test_keyframe_grid_uses_truncated_origin(oracle, bounds):
+    """KeyFrame::GetFeaturesInArea (reference src/KeyFrame.cc:732-776) subtracts the KeyFrame's
+    const int mnMinX / mnMinY (include/KeyFrame.h:411-414) on the grid the Frame built with float
+    bounds; the *_keyframe entry points against the oracle's KeyFrame variant, with the bounds of
+    a distorted camera, and the Frame forms on the same bounds beside them."""
+    import ctypes as C
+    from orb_slam2_amd._lib import FrameBounds, check, lib, ptr
+    rng = np.random.default_rng(int(abs(bounds[0]) * 10))
+    train, q, _ = _windowed_case(rng, 2200, 2600)
+    # spread part of the keypoints and queries right up to the (undistorted) image bounds
+    edge = rng.integers(0, 2200, 500)
+    train["x"][edge] = rng.uniform(bounds[0], bounds[1], 500).astype(np.float32)
+    train["y"][edge] = rng.uniform(bounds[2], bounds[3], 500).astype(np.float32)
+    qe = rng.integers(0, 2600, 800)
+    src = rng.integers(0, 2200, 800)
+    q["u"][qe] = (train["x"][src] + rng.uniform(-5, 5, 800)).astype(np.float32)
+    q["v"][qe] = (train["y"][src] + rng.uniform(-5, 5, 800)).astype(np.float32)
+    q["desc"][qe] = flip_bits(rng, train["desc"][src], 60)
+    f = lambda a, t: np.ascontiguousarray(a, t)
+    nt, nq = 2200, 2600
+    targs = [f(train["x"], "f4"), f(train["y"], "f4"), f(train["octave"], "i4"), f(train["angle"], "f4"),
+             f(train["desc"], "u1"), f(train["taken"], "u1")]
+    qa = [f(q["active"], "u1"), f(q["u"], "f4"), f(q["v"], "f4"), f(q["r"], "f4"), f(q["minl"], "i4"), f(q["maxl"], "i4"),
+          f(q["angle"], "f4"), f(q["desc"], "u1")]
+    L = lib()
+    for kf, fn in ((False, L.orb_match_windowed), (True, L.orb_match_windowed_keyframe)):
+        want_n, want_m = oracle.match_windowed(bounds, train, q, 50, True, keyframe=kf)
+        match = np.zeros(nt, np.int32); nm = C.c_int()
+        check(fn(0, FrameBounds(*bounds), nt, *[ptr(a) for a in targs], nq, *[ptr(a) for a in qa], 50, 1, ptr(match),
+                 C.byref(nm)))
+        assert nm.value == want_n and np.array_equal(match, want_m), kf
+        assert want_n > 100
+    sf, s2 = scale_tables()
+    inv = (np.float32(1) / s2).astype(np.float32)
+    lvl = np.clip(q["maxl"], 0, 7).astype(np.int32)
+    qd = dict(active=q["active"], u=q["u"], v=q["v"], r=q["r"], level=lvl, desc=q["desc"])
+    tb = [f(train["x"], "f4"), f(train["y"], "f4"), f(train["octave"], "i4"), f(train["desc"], "u1")]
+    qb = [f(q["active"], "u1"), f(q["u"], "f4"), f(q["v"], "f4"), f(q["r"], "f4"), lvl, f(q["desc"], "u1")]
+    for kf, fn in ((False, L.orb_window_best), (True, L.orb_window_best_keyframe)):
+        wbi, wbd = oracle.window_best(bounds, train, qd, inv, 5.99, keyframe=kf)
+        bi, bd = np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+        check(fn(0, FrameBounds(*bounds), nt, *[ptr(a) for a in tb], ptr(inv), 8, 5.99, nq, *[ptr(a) for a in qb], ptr(bi),
+                 ptr(bd)))
+        assert np.array_equal(bi, wbi) and np.array_equal(bd, wbd), kf
