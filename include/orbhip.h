@@ -113,6 +113,18 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
  * (R*9798 + G*19235 + B*3735 + 2^14) >> 15; alpha is ignored. */
 int orb_extractor_set_input_format(OrbExtractor* h, int channels, int rgb_order);
 
+/* The OpenCV release whose arithmetic the handle reproduces from now on.  The reference links
+ * whatever OpenCV its build finds (CMakeLists.txt:20, no version pinned), and two primitives on
+ * this path changed between releases:
+ *   cv::GaussianBlur 7x7 sigma 2, 8-bit (src/ORBextractor.cc:1300): fixed-point taps
+ *     18 34 48 56 48 34 18 (sum 256) from 4.5 on; 18 34 49 55 49 34 18 (every tap rounded, sum 257,
+ *     results saturated) in 3.4 and 4.0 - 4.4;
+ *   cv::cvtColor to grey (src/Tracking.cc:203-216, see orb_extractor_set_input_format): 15-bit
+ *     weights from 4.0 on, 14-bit weights (R*4899 + G*9617 + B*1868 + 2^13) >> 14 before.
+ * Default: 4.5 and later.  Releases before 3.4 blur in floating point and are refused with
+ * ORBHIP_ERR_UNSUPPORTED.  No counterpart in the reference. */
+int orb_extractor_set_opencv_compat(OrbExtractor* h, int major, int minor);
+
 /* Waits for the handle's own stream, which the host-buffer entry points and the
  * accessors below use. */
 int orb_extractor_sync(OrbExtractor* h);

@@ -99,6 +99,11 @@ def fast9_16(img, threshold):
     return out[:n].copy()
 
 
+def set_opencv_compat(major, minor):
+    """Process-wide: the OpenCV release whose blur taps and grey weights are restated (default 4.5+)."""
+    lib().orc_set_opencv_compat(C.c_int(int(major)), C.c_int(int(minor)))
+
+
 def gaussian_taps():
     t = np.zeros(7, np.int32)
     lib().orc_gaussian_taps_7_s2(_p(t))

@@ -181,6 +181,14 @@ ORC_API int orc_fast9_16(const uint8_t* img, int w, int h, int stride, int thres
   return n;
 }
 
+/* ---- the OpenCV release being restated -------------------------------------- */
+/* The reference links whatever OpenCV its build finds (CMakeLists.txt:20).  Two primitives on
+ * this path changed between releases: the fixed-point taps of GaussianBlur (error diffusion
+ * from 4.5 on, every tap rounded on its own in 3.4 and 4.0 - 4.4) and the grey weights of
+ * cvtColor (15 bits from 4.0 on, 14 bits before).  Process-wide switch, default 4.5+. */
+static int g_cv_major = 4, g_cv_minor = 5;
+ORC_API void orc_set_opencv_compat(int major, int minor) { g_cv_major = major; g_cv_minor = minor; }
+
 /* ---- cv::GaussianBlur(8U, 7x7, sigma 2, BORDER_REFLECT_101), fixed point --- */
 /* Called at ORBextractor.cc:1300-1305 on a continuous clone.  OpenCV >= 4.5's
  * 8-bit path: taps in unsigned 8.8 fixed point with error diffusion so that they
@@ -192,6 +200,11 @@ ORC_API void orc_gaussian_taps_7_s2(int* taps /* 7 */) {
   for (int i = 0; i < 7; i++) { double x = i - 3.0; k[i] = exp(scale2x * x * x); sum += k[i]; }
   sum = 1. / sum;
   for (int i = 0; i < 7; i++) k[i] *= sum;
+  if (!(g_cv_major > 4 || (g_cv_major == 4 && g_cv_minor >= 5))) {
+    /* before 4.5: each tap rounded on its own (18 34 49 55 49 34 18, sum 257) */
+    for (int i = 0; i < 7; i++) taps[i] = cv_round_d(k[i] * 256.0);
+    return;
+  }
   double err = 0;
   int64_t s = 0;
   for (int i = 0; i < 3; i++) {
@@ -1397,12 +1410,13 @@ ORC_API int orc_bow_vector_l1(int n, const int* word_id, const double* w, int* o
  * weights 4899, 9617, 1868: a few pixels differ by one.)  Alpha is ignored. */
 ORC_API void orc_cvt_gray(const uint8_t* src, int rows, int cols, int stride, int channels, int rgb_order,
                           uint8_t* dst /* rows x cols, packed */) {
-  const int kr = 9798, kg = 19235, kb = 3735;
+  const int shift = g_cv_major >= 4 ? 15 : 14;
+  const int kr = shift == 15 ? 9798 : 4899, kg = shift == 15 ? 19235 : 9617, kb = shift == 15 ? 3735 : 1868;
   for (int y = 0; y < rows; y++)
     for (int x = 0; x < cols; x++) {
       const uint8_t* p = src + (size_t)y * stride + (size_t)x * channels;
       const int r = rgb_order ? p[0] : p[2], g = p[1], b = rgb_order ? p[2] : p[0];
-      dst[(size_t)y * cols + x] = (uint8_t)((r * kr + g * kg + b * kb + (1 << 14)) >> 15);
+      dst[(size_t)y * cols + x] = (uint8_t)((r * kr + g * kg + b * kb + (1 << (shift - 1))) >> shift);
     }
 }
 

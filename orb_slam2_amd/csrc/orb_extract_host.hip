@@ -16,7 +16,7 @@ namespace orbhip {
 
 // launchers and limits defined next to the kernels
 void launch_pyr_level0(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, int, hipStream_t);
-void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, uint8_t*, const Plan&, int, hipStream_t);
+void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, const int*, uint8_t*, const Plan&, int, hipStream_t);
 void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
 void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, uint32_t*, int*, int, int, int, hipStream_t);
 hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, int, hipStream_t);
@@ -124,7 +124,8 @@ struct OrbExtractor {
   float sf[kMaxLevels], inv_sf[kMaxLevels], sigma2[kMaxLevels], inv_sigma2[kMaxLevels];
   int quota[kMaxLevels];
   int umax[16];
-  int taps[4];
+  int taps[4];  // first four taps of the 7-tap blur kernel (it is symmetric), 8.8 fixed point
+  int gray[4];  // cvtColor weights R, G, B and their shift
   hipStream_t stream = nullptr;
 
   // plan for the current image size
@@ -414,7 +415,7 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   ORB_HIP_CHECK(hipMemsetAsync(h->d_cand_cnt, 0, sizeof(int) * (size_t)P.nlevels * nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[0], st));
   if (h->channels == 1) launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, nframes, st);
-  else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->d_pyr, P, nframes, st);
+  else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->gray, h->d_pyr, P, nframes, st);
   for (int l = 1; l < P.nlevels; l++) {
     const OrbExtractor::TileInfo& ti = h->tile[l];
     if (ti.ok)
@@ -436,6 +437,33 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   ORB_HIP_CHECK(hipGetLastError());
   h->last_frames = nframes;
   return ORBHIP_OK;
+}
+
+// The two pieces of OpenCV arithmetic on this path that changed between releases.
+//  * cv::GaussianBlur, 8-bit fixed-point path: the 7-tap sigma-2 kernel in 8.8 fixed point.  From
+//    4.5 on the rounding error of a tap is carried to the next one and the centre tap takes the
+//    remainder, so the taps sum to 256: 18 34 48 56 48 34 18.  4.0 - 4.4 (and 3.4 since the
+//    fixed-point path appeared) round every tap on its own: 18 34 49 55 49 34 18, sum 257,
+//    results saturated.
+//  * cv::cvtColor to grey, 8-bit: 15-bit weights 9798 / 19235 / 3735 from 4.0 on, 14-bit weights
+//    4899 / 9617 / 1868 before.
+void set_opencv_tables(OrbExtractor* h, int major, int minor) {
+  double k[7], s = 0;
+  for (int i = 0; i < 7; i++) { const double x = i - 3.0; k[i] = exp(-0.125 * x * x); s += k[i]; }
+  s = 1.0 / s;
+  if (major > 4 || (major == 4 && minor >= 5)) {
+    double err = 0; int acc = 0;
+    for (int i = 0; i < 3; i++) {
+      const double adj = k[i] * s * 256.0 + err;
+      const int v = cv_round(adj);
+      err = adj - v; h->taps[i] = v; acc += v;
+    }
+    h->taps[3] = 256 - 2 * acc;
+  } else {
+    for (int i = 0; i < 4; i++) h->taps[i] = cv_round(k[i] * s * 256.0);
+  }
+  if (major >= 4) { h->gray[0] = 9798; h->gray[1] = 19235; h->gray[2] = 3735; h->gray[3] = 15; }
+  else { h->gray[0] = 4899; h->gray[1] = 9617; h->gray[2] = 1868; h->gray[3] = 14; }
 }
 
 struct DeviceGuard {
@@ -494,20 +522,7 @@ int orb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini
     static const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     if (memcmp(expect, h->umax, sizeof(expect)) != 0) { delete h; set_error("umax table mismatch"); return ORBHIP_ERR_UNSUPPORTED; }
   }
-  // 7-tap sigma-2 Gaussian in 8.8 fixed point, rounding error carried to the next tap,
-  // centre tap takes the remainder so that the taps sum to 256
-  {
-    double k[7], s = 0;
-    for (int i = 0; i < 7; i++) { const double x = i - 3.0; k[i] = exp(-0.125 * x * x); s += k[i]; }
-    s = 1.0 / s;
-    double err = 0; int acc = 0;
-    for (int i = 0; i < 3; i++) {
-      const double adj = k[i] * s * 256.0 + err;
-      const int v = cv_round(adj);
-      err = adj - v; h->taps[i] = v; acc += v;
-    }
-    h->taps[3] = 256 - 2 * acc;
-  }
+  set_opencv_tables(h, 4, 5);
   DeviceGuard g(device_id);
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate"); }
@@ -583,6 +598,16 @@ int orb_extractor_set_input_format(OrbExtractor* h, int channels, int rgb_order)
   if (channels != 1 && channels != 3 && channels != 4) { set_error("channels must be 1, 3 or 4"); return ORBHIP_ERR_ARG; }
   h->channels = channels;
   h->rgb_order = rgb_order != 0;
+  return ORBHIP_OK;
+}
+
+int orb_extractor_set_opencv_compat(OrbExtractor* h, int major, int minor) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  if (major < 3 || (major == 3 && minor < 4) || minor < 0) {
+    set_error("OpenCV before 3.4 blurs 8-bit images in floating point; that path is not restated here");
+    return ORBHIP_ERR_UNSUPPORTED;
+  }
+  set_opencv_tables(h, major, minor);
   return ORBHIP_OK;
 }
 

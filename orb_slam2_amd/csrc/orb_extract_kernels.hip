@@ -87,14 +87,15 @@ __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restri
 // Level 0 from an interleaved colour image: cv::cvtColor(..., CV_RGB2GRAY / CV_BGR2GRAY /
 // CV_RGBA2GRAY / CV_BGRA2GRAY) of the reference's Tracking::GrabImage* (src/Tracking.cc:203-216)
 // folded into the copy above, so the grey image never exists in memory.  8-bit cvtColor is
-// integer: (c0*k0 + c1*k1 + c2*k2 + 2^14) >> 15 with the 15-bit BT.601 weights
-// R 9798, G 19235, B 3735 (they sum to 2^15, so the result fits a byte); alpha is ignored.
+// integer: (c0*k0 + c1*k1 + c2*k2 + 2^(s-1)) >> s with BT.601 weights that sum to 2^s, so the
+// result fits a byte: s = 15, R 9798, G 19235, B 3735 in OpenCV 4.x; s = 14, 4899 / 9617 / 1868
+// before.  Alpha is ignored.
 // A thread writes 16 slab bytes from 16*CH source bytes of any alignment.
 template <int CH>
 __global__ __launch_bounds__(256) void pyr_level0_color_kernel(const uint8_t* __restrict__ img, size_t stride,
                                                                size_t frame_stride, uint8_t* __restrict__ pyr,
                                                                unsigned long long slab, LevelGeom L, int k0, int k1,
-                                                               int k2) {
+                                                               int k2, int rnd, int shift) {
   const int nchunk = L.pitch >> 4;
   const int t = blockIdx.y * 256 + threadIdx.x;
   const int row = t / nchunk;  // padded row
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void pyr_level0_color_kernel(const uint8_t* __
       const int c0 = (w[b >> 2] >> (8 * (b & 3))) & 255;
       const int c1 = (w[(b + 1) >> 2] >> (8 * ((b + 1) & 3))) & 255;
       const int c2 = (w[(b + 2) >> 2] >> (8 * ((b + 2) & 3))) & 255;
-      o[k >> 2] |= (uint32_t)((c0 * k0 + c1 * k1 + c2 * k2 + (1 << 14)) >> 15) << (8 * (k & 3));
+      o[k >> 2] |= (uint32_t)((c0 * k0 + c1 * k1 + c2 * k2 + rnd) >> shift) << (8 * (k & 3));
     }
   } else {
 #pragma unroll
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void pyr_level0_color_kernel(const uint8_t* __
       const int px = px0 + k;
       if (px >= -kEdge && px < L.w + kEdge) {
         const uint8_t* c = S + (size_t)refl101(px, L.w) * CH;
-        o[k >> 2] |= (uint32_t)((c[0] * k0 + c[1] * k1 + c[2] * k2 + (1 << 14)) >> 15) << (8 * (k & 3));
+        o[k >> 2] |= (uint32_t)((c[0] * k0 + c[1] * k1 + c[2] * k2 + rnd) >> shift) << (8 * (k & 3));
       }
     }
   }
@@ -974,6 +975,9 @@ __device__ __forceinline__ uint32_t blur_dot2(uint32_t a, uint32_t b, uint32_t c
 // Row pass with v_dot4_u32_u8 (taps are bytes), two image rows per thread so that the
 // 8.8 results of vertically adjacent rows share a dword; column pass with
 // v_dot2_u32_u16 on those row pairs.
+// SAT: the taps sum to more than 256 (OpenCV 4.0 - 4.4 rounds every tap: 18 34 49 55 49 34 18),
+// so a result can pass 255 and is saturated like cv::saturate_cast does.
+template <bool SAT>
 __global__ __launch_bounds__(B_THREADS) void blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                                          Plan P, const BlurItem* __restrict__ items, int nitems,
                                                          int fchunk, int nframes, int t0, int t1, int t2, int t3) {
@@ -1032,10 +1036,11 @@ __global__ __launch_bounds__(B_THREADS) void blur_kernel(const uint8_t* __restri
     const uint32_t tp0 = odd ? TPo0 : TPe0, tp1 = odd ? TPo1 : TPe1, tp2 = odd ? TPo2 : TPe2, tp3 = odd ? TPo3 : TPe3;
     const uint4* hp = reinterpret_cast<const uint4*>(&s_hp[(y >> 1) * B_TW + 4 * c]);
     const uint4 v0 = hp[0], v1 = hp[B_TW / 4], v2 = hp[2 * (B_TW / 4)], v3 = hp[3 * (B_TW / 4)];
-    const uint32_t a0 = blur_dot2(v3.x, tp3, blur_dot2(v2.x, tp2, blur_dot2(v1.x, tp1, blur_dot2(v0.x, tp0, 32768u))));
-    const uint32_t a1 = blur_dot2(v3.y, tp3, blur_dot2(v2.y, tp2, blur_dot2(v1.y, tp1, blur_dot2(v0.y, tp0, 32768u))));
-    const uint32_t a2 = blur_dot2(v3.z, tp3, blur_dot2(v2.z, tp2, blur_dot2(v1.z, tp1, blur_dot2(v0.z, tp0, 32768u))));
-    const uint32_t a3 = blur_dot2(v3.w, tp3, blur_dot2(v2.w, tp2, blur_dot2(v1.w, tp1, blur_dot2(v0.w, tp0, 32768u))));
+    uint32_t a0 = blur_dot2(v3.x, tp3, blur_dot2(v2.x, tp2, blur_dot2(v1.x, tp1, blur_dot2(v0.x, tp0, 32768u))));
+    uint32_t a1 = blur_dot2(v3.y, tp3, blur_dot2(v2.y, tp2, blur_dot2(v1.y, tp1, blur_dot2(v0.y, tp0, 32768u))));
+    uint32_t a2 = blur_dot2(v3.z, tp3, blur_dot2(v2.z, tp2, blur_dot2(v1.z, tp1, blur_dot2(v0.z, tp0, 32768u))));
+    uint32_t a3 = blur_dot2(v3.w, tp3, blur_dot2(v2.w, tp2, blur_dot2(v1.w, tp1, blur_dot2(v0.w, tp0, 32768u))));
+    if (SAT) { a0 = min(a0, 0xFFFFFFu); a1 = min(a1, 0xFFFFFFu); a2 = min(a2, 0xFFFFFFu); a3 = min(a3, 0xFFFFFFu); }
     // results are < 2^24: byte 2 of each accumulator is the output pixel
     const uint32_t o = ((a0 >> 16) & 0xFF) | ((a1 >> 8) & 0xFF00) | (a2 & 0xFF0000) | ((a3 << 8) & 0xFF000000u);
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch) = o;
@@ -1330,18 +1335,19 @@ void launch_pyr_level0(const uint8_t* img, size_t stride, size_t frame_stride, u
   hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L);
 }
 void launch_pyr_level0_color(const uint8_t* img, size_t stride, size_t frame_stride, int channels, bool rgb_order,
-                             uint8_t* pyr, const Plan& P, int nframes, hipStream_t st) {
+                             const int* gray /* weight R, G, B, shift */, uint8_t* pyr, const Plan& P, int nframes,
+                             hipStream_t st) {
   const LevelGeom& L = P.lv[0];
   const int pieces = (L.pitch / 16) * (L.h + 2 * kEdge);
   dim3 grid(nframes, (pieces + 255) / 256);
-  const int kr = 9798, kg = 19235, kb = 3735;
+  const int kr = gray[0], kg = gray[1], kb = gray[2], shift = gray[3], rnd = 1 << (shift - 1);
   const int k0 = rgb_order ? kr : kb, k2 = rgb_order ? kb : kr;
   if (channels == 3)
     hipLaunchKernelGGL(pyr_level0_color_kernel<3>, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, k0,
-                       kg, k2);
+                       kg, k2, rnd, shift);
   else
     hipLaunchKernelGGL(pyr_level0_color_kernel<4>, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, k0,
-                       kg, k2);
+                       kg, k2, rnd, shift);
 }
 void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, const YTab* yt, int nframes,
                        hipStream_t st) {
@@ -1407,8 +1413,12 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurIte
   while ((long long)nitems * ((nframes + fchunk - 1) / fchunk) > 65535) fchunk *= 2;  // grid.y limit
   fchunk = min(fchunk, nframes);
   const int nchunks = (nframes + fchunk - 1) / fchunk;
-  hipLaunchKernelGGL(blur_kernel, dim3(fchunk, nitems * nchunks), dim3(B_THREADS), 0, st, pyr, blur, P, items, nitems,
-                     fchunk, nframes, taps[0], taps[1], taps[2], taps[3]);
+  if (taps[3] + 2 * (taps[0] + taps[1] + taps[2]) > 256)
+    hipLaunchKernelGGL(blur_kernel<true>, dim3(fchunk, nitems * nchunks), dim3(B_THREADS), 0, st, pyr, blur, P, items,
+                       nitems, fchunk, nframes, taps[0], taps[1], taps[2], taps[3]);
+  else
+    hipLaunchKernelGGL(blur_kernel<false>, dim3(fchunk, nitems * nchunks), dim3(B_THREADS), 0, st, pyr, blur, P, items,
+                       nitems, fchunk, nframes, taps[0], taps[1], taps[2], taps[3]);
 }
 void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel, const int* sel_cnt, const Plan& P,
                         OrbKeyPoint* kps, uint8_t* desc, int* n_out, int max_kp, int nframes, hipStream_t st) {

@@ -85,6 +85,11 @@ class ORBextractor:
         check(self._lib.orb_extractor_set_input_format(self._h, int(channels), int(bool(rgb_order))))
         self._channels = int(channels)
 
+    def set_opencv_compat(self, major, minor):
+        """Reproduce the arithmetic of this OpenCV release (blur taps, grey weights): the
+        reference links whichever OpenCV its build finds."""
+        check(self._lib.orb_extractor_set_opencv_compat(self._h, int(major), int(minor)))
+
     def extract_batch(self, images):
         """images: (n, rows, cols) uint8 grey, or (n, rows, cols, 3|4) colour in the order
         self.mbRGB says.  Returns lists of per-frame keypoints/descriptors."""

@@ -341,3 +341,38 @@ def test_colour_device_path_strided_batch(oracle):
     with pytest.raises(OrbHipError):
         ex.extract_batch_device(d.data_ptr(), n, rows, cols, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(), cap,
                                 stride=cols, frame_stride=fstride)
+
+
+@pytest.mark.parametrize("major,minor", [(4, 2), (3, 4), (4, 8)])
+def test_opencv_release_switch(oracle, major, minor):
+    """orb_extractor_set_opencv_compat: the blur taps of OpenCV 3.4 / 4.0 - 4.4 (every tap rounded,
+    sum 257, saturated results) and the 14-bit grey weights of 3.x, against the oracle set to the
+    same release; 4.5+ is the default and gives the default's results."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd._lib import OrbHipError
+    rows, cols = 300, 420
+    img = _colour_image(rows, cols, 3, 9)
+    img[40:80, 50:120] = 255  # a saturated patch: with taps summing to 257 the blur must clip at 255
+    ex = ORBextractor(900, 1.2, 8, 20, 7)
+    ex.set_opencv_compat(major, minor)
+    try:
+        oracle.set_opencv_compat(major, minor)
+        taps = list(oracle.gaussian_taps())
+        assert taps == ([18, 34, 48, 56, 48, 34, 18] if (major, minor) >= (4, 5) else [18, 34, 49, 55, 49, 34, 18])
+        gray = oracle.cvt_gray(img, True)
+        ref = oracle.Extractor(900, 1.2, 8, 20, 7)
+        rk, rd = ref(gray)
+        kps, desc = ex(img)
+        assert np.array_equal(ex.pyramid_level(0), gray)
+        assert len(rk) > 50
+        check_against(kps, desc, rk, rd)
+        check_stages(ex, ref, 8)
+        assert ex.blurred_level(0)[45:75, 60:110].max() == 255
+    finally:
+        oracle.set_opencv_compat(4, 5)
+    if (major, minor) < (4, 5):  # and the releases really differ on this image
+        d = ORBextractor(900, 1.2, 8, 20, 7)
+        d(img)
+        assert not np.array_equal(d.blurred_level(0), ex.blurred_level(0))
+    with pytest.raises(OrbHipError):
+        ex.set_opencv_compat(2, 4)

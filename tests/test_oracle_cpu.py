@@ -407,3 +407,23 @@ def test_distinctive_descriptor_known_answers(oracle):
     assert oracle.distinctive_descriptor(d2) == (2, 0)
     assert oracle.distinctive_descriptor(d[:1]) == (0, 0)
     assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == (-1, -1)
+
+
+def test_opencv_release_switch_taps_and_grey_weights(oracle):
+    """The two release-dependent pieces of arithmetic: blur taps (sum 256 from OpenCV 4.5 on,
+    each tap rounded before: sum 257, saturated) and grey weights (15 bits from 4.0 on)."""
+    try:
+        oracle.set_opencv_compat(4, 4)
+        t = oracle.gaussian_taps()
+        assert list(t) == [18, 34, 49, 55, 49, 34, 18] and t.sum() == 257
+        assert (oracle.gaussian_blur(np.full((16, 16), 255, np.uint8)) == 255).all()
+        c = np.full((16, 16), 100, np.uint8)
+        assert (oracle.gaussian_blur(c) == (100 * 257 * 257 + 32768) >> 16).all()
+        px = np.array([[[200, 17, 93]]], np.uint8)
+        assert oracle.cvt_gray(px)[0, 0] == (200 * 9798 + 17 * 19235 + 93 * 3735 + 16384) >> 15
+        oracle.set_opencv_compat(3, 4)
+        assert oracle.cvt_gray(px)[0, 0] == (200 * 4899 + 17 * 9617 + 93 * 1868 + 8192) >> 14
+        assert list(oracle.gaussian_taps()) == [18, 34, 49, 55, 49, 34, 18]
+    finally:
+        oracle.set_opencv_compat(4, 5)
+    assert list(oracle.gaussian_taps()) == [18, 34, 48, 56, 48, 34, 18]
