@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--knn-reps", type=int, default=3, help="timed repetitions of the kNN-2 leg (the median is reported)")
     ap.add_argument("--knn-popcount", type=int, default=1, help="1: also time the popcount kernel once on the same input")
+    ap.add_argument("--knn-comm", choices=["torch", "rccl"], default="torch",
+                    help="exchange of the sharded kNN-2 for N > 1: torch.distributed all_gather + orb_knn2_merge_device "
+                         "(the code the gloo test runs), or the library's own orb_knn2_sharded (ncclAllGather inside)")
     ap.add_argument("--host-reps", type=int, default=5, help="repetitions of the host-buffer batch call (0 = skip)")
     args = ap.parse_args()
 
@@ -199,11 +202,17 @@ def main():
         small = min(nq, 65536)
         check(L.orb_knn2_device(local, d_q.data_ptr(), small, d_db.data_ptr(), min(hi - lo, 65536), lo, 0.7,
                                 res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), None, stream))  # warm-up
+        rk = None
+        if args.knn_comm == "rccl" or world == 1:
+            rk = odist.RcclKnn(local, rank, world)
         times = []
         for _ in range(max(args.knn_reps, 1)):
             barrier()
             tk0 = time.perf_counter()
-            out, acc = odist.knn2_sharded(local_search, merge, nq, dev, world)
+            if args.knn_comm == "rccl":
+                out, acc = rk.search(d_q, d_db, lo, 0.7, stream)
+            else:
+                out, acc = odist.knn2_sharded(local_search, merge, nq, dev, world)
             barrier()
             tk = torch.tensor([time.perf_counter() - tk0], dtype=torch.float64, device=dev)
             if world > 1:
@@ -215,6 +224,18 @@ def main():
                "seconds_all": [round(t, 4) for t in times],
                "matches_per_s": round(nq / tk, 1), "pairs_per_s": round(pairs / tk, 1),
                "accepted": int(acc.sum().item())}
+        knn["exchange"] = args.knn_comm
+        if rk is not None and args.knn_comm != "rccl":
+            # one GPU: the library's own sharded entry point on a communicator of one rank, same input
+            o2, a2 = rk.search(d_q, d_db, lo, 0.7, stream)  # allocates its exchange buffers
+            barrier()
+            tk0 = time.perf_counter()
+            o2, a2 = rk.search(d_q, d_db, lo, 0.7, stream)
+            barrier()
+            knn["c_abi_sharded"] = {"seconds": round(time.perf_counter() - tk0, 4),
+                                    "identical": bool(torch.equal(o2, out) and torch.equal(a2, acc))}
+        if rk is not None:
+            rk.close()
         mfma = hi - lo >= 2048 and nq >= 256
         if mfma:
             # the matrix-core kernel: one descriptor pair = 256 int8 multiply-adds

@@ -416,6 +416,30 @@ int orb_knn2_device_algo(int device_id, const uint8_t* d_q, int n_q, const uint8
 int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_best,
                           const int* d_second, const int* d_idx, float ratio, int* d_out_best,
                           int* d_out_second, int* d_out_idx, uint8_t* d_out_accept, void* stream);
+/* The same search with the database sharded over the GPUs of a node, one process (rank) per GPU.
+ * No counterpart in the reference, which has no multi-device code.  Rank r holds the database
+ * rows [db_index_base, db_index_base + n_db_shard): the shards are contiguous and ascend with
+ * the rank; the queries are replicated.  orb_knn2_sharded scans the local shard, exchanges the
+ * per-query (best, second, index) triples with ONE ncclAllGather (12 bytes x n_q per rank, RCCL
+ * over xGMI) and merges them in rank order, so every rank ends up with the result of a single
+ * scan of the whole database, bit for bit (the earlier shard keeps ties).  Everything is enqueued
+ * on `stream`; the first call, and a call with more queries than any before, allocates the
+ * exchange buffers (3 * n_q * (world + 1) ints) and waits for the stream first.
+ *   orb_knn2_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the
+ *                             other ranks by its own means (MPI, a file, torch.distributed ...)
+ *   orb_knn2_comm_create      every rank, collectively (ncclCommInitRank) on GPU device_id
+ *   orb_knn2_comm_wrap        instead: use a communicator (ncclComm_t) the host already has
+ * RCCL is loaded at run time (librccl.so.1); ORBHIP_ERR_UNSUPPORTED if it is not there. */
+typedef struct OrbKnnComm OrbKnnComm;
+#define ORBHIP_KNN_UNIQUE_ID_BYTES 128
+int orb_knn2_comm_unique_id(uint8_t* id /* ORBHIP_KNN_UNIQUE_ID_BYTES */);
+int orb_knn2_comm_create(const uint8_t* id, int rank, int world, int device_id, OrbKnnComm** out);
+int orb_knn2_comm_wrap(void* nccl_comm, int rank, int world, int device_id, OrbKnnComm** out);
+void orb_knn2_comm_destroy(OrbKnnComm* c);
+int orb_knn2_sharded(OrbKnnComm* c, const uint8_t* d_q, int n_q, const uint8_t* d_db_shard,
+                     int n_db_shard, int db_index_base, float ratio, int* d_best, int* d_second,
+                     int* d_idx, uint8_t* d_accept, void* stream);
+
 /* Host-buffer convenience wrapper around orb_knn2_device on one GPU. */
 int orb_knn2_bruteforce(int device_id, const uint8_t* q, int n_q, const uint8_t* db, int n_db,
                         float ratio, int* best, int* second, int* idx, uint8_t* accept);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
 
 // Merge of per-shard results, shards in ascending database order: equals one scan of
 // the concatenated database (earlier shard keeps ties).
-__global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, const int* __restrict__ best,
+__global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, size_t stride, const int* __restrict__ best,
                                                          const int* __restrict__ second, const int* __restrict__ idx,
                                                          float ratio, int* __restrict__ ob, int* __restrict__ os,
                                                          int* __restrict__ oi, uint8_t* __restrict__ oa) {
@@ -156,12 +156,19 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(int nshards, int nq, co
   if (i >= nq) return;
   int bd = 256, sd = 256, bi = -1;
   for (int s = 0; s < nshards; s++) {
-    const int cb = best[(size_t)s * nq + i], cs = second[(size_t)s * nq + i], ci = idx[(size_t)s * nq + i];
+    const int cb = best[s * stride + i], cs = second[s * stride + i], ci = idx[s * stride + i];  // stride: entries from one shard to the next
     if (ci >= 0 && cb < bd) { sd = min(bd, cs); bd = cb; bi = ci; }
     else if (ci >= 0) sd = min(sd, cb);
   }
   ob[i] = bd; os[i] = sd; oi[i] = bi;
   if (oa) oa[i] = (uint8_t)(bi >= 0 && (float)bd < __fmul_rn(ratio, (float)sd));
+}
+
+hipError_t launch_knn2_merge(int nshards, int nq, size_t shard_stride, const int* best, const int* second, const int* idx,
+                             float ratio, int* ob, int* os, int* oi, uint8_t* oa, hipStream_t st) {
+  hipLaunchKernelGGL(knn2_merge_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, nshards, nq, shard_stride, best, second,
+                     idx, ratio, ob, os, oi, oa);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -1130,9 +1137,8 @@ int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_bes
   if (n_q <= 0) return ORBHIP_OK;
   if (n_shards < 1 || !d_best || !d_second || !d_idx || !d_out_best || !d_out_second || !d_out_idx) { set_error("null argument"); return ORBHIP_ERR_ARG; }
   DevSel g(device_id);
-  hipLaunchKernelGGL(knn2_merge_kernel, dim3((n_q + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_shards, n_q,
-                     d_best, d_second, d_idx, ratio, d_out_best, d_out_second, d_out_idx, d_out_accept);
-  ORB_HIP_CHECK(hipGetLastError());
+  ORB_HIP_CHECK(launch_knn2_merge(n_shards, n_q, (size_t)n_q, d_best, d_second, d_idx, ratio, d_out_best, d_out_second,
+                                  d_out_idx, d_out_accept, (hipStream_t)stream));
   return ORBHIP_OK;
 }
 

@@ -59,3 +59,51 @@ def hip_merge(ratio, device_index, stream=0):
                                            acc.data_ptr(), stream))
         return out, acc
     return run
+
+
+class RcclKnn:
+    """The same exchange through the library's own C entry points (orb_knn2_comm_* /
+    orb_knn2_sharded: shard scan, ncclAllGather, merge, all enqueued on one stream), for hosts
+    that are not Python; torch.distributed only carries the 128-byte communicator id from
+    rank 0 to the other ranks here."""
+
+    def __init__(self, device_index, rank=0, world=1, group=None):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+        self._lib = _lib
+        self.L = _lib.lib()
+        self.rank, self.world, self.device_index = rank, world, device_index
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            _lib.check(self.L.orb_knn2_comm_unique_id(uid.ctypes.data))
+        if world > 1:
+            t = torch.from_numpy(uid).to(torch.device("cuda", device_index) if dist.get_backend(group) == "nccl" else "cpu")
+            dist.broadcast(t, src=0, group=group)
+            uid = t.cpu().numpy()
+        h = C.c_void_p()
+        _lib.check(self.L.orb_knn2_comm_create(uid.ctypes.data, rank, world, device_index, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.orb_knn2_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search(self, d_q, d_db_shard, index_base, ratio, stream=0):
+        """-> (int32 [3, n_q] best / second / global index, uint8 [n_q] accept), identical on every rank."""
+        n_q = d_q.shape[0]
+        out = torch.empty((3, n_q), dtype=torch.int32, device=d_q.device)
+        acc = torch.empty(n_q, dtype=torch.uint8, device=d_q.device)
+        self._lib.check(self.L.orb_knn2_sharded(self._h, d_q.data_ptr(), n_q, d_db_shard.data_ptr(), d_db_shard.shape[0],
+                                                index_base, ratio, out[0].data_ptr(), out[1].data_ptr(),
+                                                out[2].data_ptr(), acc.data_ptr(), stream))
+        return out, acc
