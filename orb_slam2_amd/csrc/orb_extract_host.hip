@@ -169,10 +169,21 @@ struct OrbExtractor {
   bool rgb_order = true;  // first colour byte is red (the reference's Camera.RGB setting)
   std::vector<hipEvent_t> ev;  // ORBHIP_NUM_STAGES + 1 events per profiled call
   int prof_calls = 0;          // profiled calls since the times were last read
+  // The host-buffer call for a few frames is bound by launch overhead (a memset, 13 dependent
+  // kernels, four copies): its device work is captured once into a graph and replayed while
+  // nothing the graph refers to (sizes, buffers, tables) has changed.
+  hipGraphExec_t graph_exec = nullptr;
+  struct GraphKey {
+    int n_frames = 0, rows = 0, cols = 0, max_kp = 0, channels = 0, rgb = 0;
+    int taps[4] = {0, 0, 0, 0}, gray[4] = {0, 0, 0, 0};
+    const void *d_img = nullptr, *h_img = nullptr, *h_out = nullptr, *d_kps = nullptr, *d_pyr = nullptr;
+    bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
+  } graph_key;
 };
 
 namespace {
 
+constexpr int kGraphMaxFrames = 8;                 // batches up to this size replay a captured graph
 constexpr int kPoolThreads = 8;                    // host threads that pack a large batch (the caller is one)
 constexpr size_t kPoolMinBytes = (size_t)4 << 20;  // smaller batches are packed by the caller alone
 
@@ -542,6 +553,7 @@ void orb_extractor_destroy(OrbExtractor* h) {
   if (h->h_out) hipHostFree(h->h_out);
   delete h->pool;
   for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
+  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
   hipStreamDestroy(h->stream);
   delete h;
 }
@@ -690,7 +702,10 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
     if (stride == row_bytes) memcpy(dst, src, frame_bytes);
     else for (int r = 0; r < rows; r++) memcpy(dst + (size_t)r * row_bytes, src + (size_t)r * stride, row_bytes);
   };
-  if (n_frames < 4 || img_bytes < kPoolMinBytes) {
+  const bool small = n_frames <= kGraphMaxFrames && img_bytes < kPoolMinBytes;
+  if (small) {
+    for (int k = 0; k < n_frames; k++) pack(k);  // the upload is part of the replayed graph
+  } else if (n_frames < 4 || img_bytes < kPoolMinBytes) {
     for (int k = 0; k < n_frames; k++) pack(k);
     ORB_HIP_CHECK(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, st));
   } else {
@@ -705,9 +720,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
                                    (size_t)kn * frame_bytes, hipMemcpyHostToDevice, st));
     }
   }
-  rc = enqueue(h, n_frames, h->d_img, row_bytes, (size_t)rows * row_bytes, max_kp, h->d_kps, h->d_desc, h->d_nout, st);
-  if (rc != ORBHIP_OK) return rc;
-  // results come back through pinned staging as well: two DMAs for the batch, then the valid
+  // results come back through pinned staging as well: three DMAs for the batch, then the valid
   // part of every frame is copied to the caller's arrays
   const size_t out_bytes = need * (sizeof(OrbKeyPoint) + 32) + sizeof(int) * (size_t)n_frames;
   if (out_bytes > h->h_out_bytes) {
@@ -720,9 +733,40 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   OrbKeyPoint* s_kps = reinterpret_cast<OrbKeyPoint*>(h->h_out);
   uint8_t* s_desc = h->h_out + need * sizeof(OrbKeyPoint);
   int* s_n = reinterpret_cast<int*>(s_desc + need * 32);
-  ORB_HIP_CHECK(hipMemcpyAsync(s_n, h->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, st));
-  ORB_HIP_CHECK(hipMemcpyAsync(s_kps, h->d_kps, sizeof(OrbKeyPoint) * need, hipMemcpyDeviceToHost, st));
-  ORB_HIP_CHECK(hipMemcpyAsync(s_desc, h->d_desc, 32 * need, hipMemcpyDeviceToHost, st));
+  auto device_work = [&](bool with_upload) -> int {
+    if (with_upload) ORB_HIP_CHECK(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, st));
+    int r = enqueue(h, n_frames, h->d_img, row_bytes, (size_t)rows * row_bytes, max_kp, h->d_kps, h->d_desc, h->d_nout, st);
+    if (r != ORBHIP_OK) return r;
+    ORB_HIP_CHECK(hipMemcpyAsync(s_n, h->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, st));
+    ORB_HIP_CHECK(hipMemcpyAsync(s_kps, h->d_kps, sizeof(OrbKeyPoint) * need, hipMemcpyDeviceToHost, st));
+    ORB_HIP_CHECK(hipMemcpyAsync(s_desc, h->d_desc, 32 * need, hipMemcpyDeviceToHost, st));
+    return ORBHIP_OK;
+  };
+  if (small && !h->profiling) {
+    OrbExtractor::GraphKey key;
+    key.n_frames = n_frames; key.rows = rows; key.cols = cols; key.max_kp = max_kp; key.channels = h->channels;
+    key.rgb = h->rgb_order;
+    for (int i = 0; i < 4; i++) { key.taps[i] = h->taps[i]; key.gray[i] = h->gray[i]; }
+    key.d_img = h->d_img; key.h_img = h->h_img; key.h_out = h->h_out; key.d_kps = h->d_kps; key.d_pyr = h->d_pyr;
+    if (!h->graph_exec || !(key == h->graph_key)) {
+      if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      ORB_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+      rc = device_work(true);
+      hipError_t ce = hipStreamEndCapture(st, &graph);
+      if (rc != ORBHIP_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture");
+      ce = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (ce != hipSuccess) { h->graph_exec = nullptr; return hip_fail(ce, "hipGraphInstantiate"); }
+      h->graph_key = key;
+    }
+    ORB_HIP_CHECK(hipGraphLaunch(h->graph_exec, st));
+    h->last_frames = n_frames;
+  } else {
+    rc = device_work(false);
+    if (rc != ORBHIP_OK) return rc;
+  }
   ORB_HIP_CHECK(hipStreamSynchronize(st));
   int status = ORBHIP_OK;
   for (int k = 0; k < n_frames; k++) {
