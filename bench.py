@@ -324,7 +324,7 @@ def main():
         # valid for the batch size they were taken at
         traffic = {}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
             if tj["frames_per_launch"] == B:
                 traffic = {k.replace("_kernel", ""): v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
         except (OSError, ValueError, KeyError):

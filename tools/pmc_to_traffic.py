@@ -18,7 +18,7 @@ def mean_per_kernel(d, counter):
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(fn)):
             if row["Counter_Name"] == counter:
-                acc[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
+                acc[row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
