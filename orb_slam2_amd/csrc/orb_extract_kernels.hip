@@ -496,27 +496,31 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         const uint32_t R = *reinterpret_cast<const uint32_t*>(rowp + 4);
         const uint32_t U = *reinterpret_cast<const uint32_t*>(rowp - 3 * F_PITCH);
         const uint32_t D = *reinterpret_cast<const uint32_t*>(rowp + 3 * F_PITCH);
-        const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1);  // pixels x-3
-        const uint32_t E = __builtin_amdgcn_alignbyte(R, C, 3);   // pixels x+3
-        // per pixel: brighter / darker than the centre by more than t at the four compass
-        // points.  Nine contiguous ring pixels always contain two adjacent compass points:
-        // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12).  The comparisons are done per
-        // byte lane (byte-select operands), their results are wave masks combined on the scalar unit.
+        // per pixel: some ring pixel pair at the compass points is brighter / darker than the centre
+        // by more than t.  Nine contiguous ring pixels always contain two adjacent compass points:
+        // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12), for "brighter" as for "darker", i.e.
+        //   max( min(max(p0,p8), max(p4,p12)) - c,  c - max(min(p0,p8), min(p4,p12)) ) > t.
+        // Two pixels at a time on packed 16-bit lanes: v_perm spreads the bytes of the five dwords
+        // (the pixels 3 to the left / right come straight out of the neighbouring dwords).
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int c = (int)((C >> (8 * j)) & 0xFFu);
-          const int hi = c + t, lo = c - t;
-          const int p0 = (int)((D >> (8 * j)) & 0xFFu), p8 = (int)((U >> (8 * j)) & 0xFFu);
-          const int p4 = (int)((E >> (8 * j)) & 0xFFu), p12 = (int)((W >> (8 * j)) & 0xFFu);
-          const bool br = min(max(p0, p8), max(p4, p12)) > hi;
-          const bool dk = max(min(p0, p8), min(p4, p12)) < lo;
-          const bool ok = vy & mine[j] & (br | dk);
-          // the mask of `ok` from the masks of the two comparisons (a ballot of the combined
-          // predicate would be rebuilt from a select and a compare)
-          const unsigned long long m =
-              (__builtin_amdgcn_ballot_w64(br) | __builtin_amdgcn_ballot_w64(dk)) & mine_mask[j] & row_mask;
-          if (ok) s_list[wave][qn + below(m)] = (uint16_t)(rowoff + j);
-          qn += __popcll(m);
+        for (int h2 = 0; h2 < 2; h2++) {
+          const uint32_t s01 = h2 ? 0x0c030c02u : 0x0c010c00u;
+          const fast_s2 c2 = as_s2(__builtin_amdgcn_perm(0u, C, s01));
+          const fast_s2 p0 = as_s2(__builtin_amdgcn_perm(0u, D, s01)), p8 = as_s2(__builtin_amdgcn_perm(0u, U, s01));
+          const fast_s2 p12 = as_s2(__builtin_amdgcn_perm(C, Lw, h2 ? 0x0c040c03u : 0x0c020c01u));  // pixels x-3
+          const fast_s2 p4 = as_s2(__builtin_amdgcn_perm(R, C, h2 ? 0x0c060c05u : 0x0c040c03u));    // pixels x+3
+          const fast_s2 hiq = pk_min(pk_max(p0, p8), pk_max(p4, p12));
+          const fast_s2 loq = pk_max(pk_min(p0, p8), pk_min(p4, p12));
+          const fast_s2 d = pk_max(hiq - c2, c2 - loq);
+#pragma unroll
+          for (int jj = 0; jj < 2; jj++) {
+            const int j = 2 * h2 + jj;
+            const bool pass = (jj ? d.y : d.x) > (short)t;
+            const bool ok = vy & mine[j] & pass;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass) & mine_mask[j] & row_mask;
+            if (ok) s_list[wave][qn + below(m)] = (uint16_t)(rowoff + j);
+            qn += __popcll(m);
+          }
         }
         if (qn >= 64) {
           int head = 0;
