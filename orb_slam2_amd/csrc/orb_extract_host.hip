@@ -25,9 +25,10 @@ hipError_t upload_orient_tables();
 void launch_orient_desc(const uint8_t*, const uint8_t*, const uint32_t*, const int*, const Plan&, OrbKeyPoint*,
                         uint8_t*, int*, int, int, hipStream_t);
 void launch_pyr_resize_tile(uint8_t*, const Plan&, int, const uint32_t*, const YTab*, const int2*, int, const int2*, int,
-                            int, int, int, hipStream_t);
+                            int, int, int, int, hipStream_t);
 int pyr_tile_cols();
 int pyr_tile_rows();
+int pyr_tile_rows_small();
 int pyr_tile_max_src_rows();
 int pyr_tile_max_src_bytes();
 int fast_use_width();
@@ -136,7 +137,10 @@ struct OrbExtractor {
   int ot_slots = 0;    // quad-tree node slots the largest level needs
   // tiled resize: per level, packed column table (one entry per slab column) and the
   // source ranges of every tile column / tile row; tile_ok[l] = the tiled kernel applies
-  struct TileInfo { bool ok = false; int xtp_off = 0, xr_off = 0, yr_off = 0, ngx = 0, ngy = 0, src_rows = 0, src_pitch = 0; };
+  // yr_off / ngy / src_rows exist twice: [0] for tiles of pyr_tile_rows() rows (batches), [1] for the
+  // short tiles of pyr_tile_rows_small() rows that a few frames are cut into, so that a level of one
+  // frame is spread over many workgroups instead of waiting for a handful of long ones
+  struct TileInfo { bool ok = false; int xtp_off = 0, xr_off = 0, ngx = 0, src_pitch = 0; int yr_off[2] = {0, 0}, ngy[2] = {0, 0}, src_rows[2] = {0, 0}; };
   TileInfo tile[kMaxLevels];
   uint32_t* d_xtp = nullptr;
   int2* d_ranges = nullptr;
@@ -183,6 +187,7 @@ struct OrbExtractor {
 
 namespace {
 
+constexpr int kSmallBatchFrames = 8;               // up to this many frames a launch is cut into more, smaller workgroups
 constexpr int kGraphMaxFrames = 8;                 // batches up to this size replay a captured graph
 constexpr int kPoolThreads = 8;                    // host threads that pack a large batch (the caller is one)
 constexpr size_t kPoolMinBytes = (size_t)4 << 20;  // smaller batches are packed by the caller alone
@@ -344,12 +349,12 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
       const LevelGeom& S = P.lv[l - 1];
       OrbExtractor::TileInfo ti;
       ti.xtp_off = (int)xtp.size();
-      const int TC = pyr_tile_cols(), TR = pyr_tile_rows();
+      const int TC = pyr_tile_cols();
+      const int TRv[2] = {pyr_tile_rows(), pyr_tile_rows_small()};
       ti.ngx = (L.pitch + TC - 1) / TC;
-      ti.ngy = (L.h + 2 * kEdge + TR - 1) / TR;
       auto refl = [](int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; };
       const int ncol = ti.ngx * TC;
-      std::vector<int2> xr(ti.ngx, make_int2(1 << 30, -1)), yr(ti.ngy, make_int2(1 << 30, -1));
+      std::vector<int2> xr(ti.ngx, make_int2(1 << 30, -1));
       bool weights_ok = true;
       for (int c = 0; c < ncol; c++) {
         const int px = c - kXOff;
@@ -368,11 +373,6 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
         }
         xtp.push_back(e);
       }
-      for (int r = 0; r < L.h + 2 * kEdge; r++) {
-        const YTab& t = ytab[L.ytab_off + refl(r - kEdge, L.h)];
-        int2& q = yr[r / TR];
-        q.x = std::min(q.x, (int)std::min(t.sy0, t.sy1)); q.y = std::max(q.y, (int)std::max(t.sy0, t.sy1));
-      }
       ti.ok = weights_ok;
       for (int2& r : xr) {
         if (r.y < 0) { r.x = 0; r.y = 0; }
@@ -381,12 +381,22 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
         ti.src_pitch = std::max(ti.src_pitch, bytes);
         if (bytes > pyr_tile_max_src_bytes() || r.y + kXOff + 16 > S.pitch) ti.ok = false;
       }
-      for (int2& r : yr) {
-        ti.src_rows = std::max(ti.src_rows, r.y - r.x + 1);
-        if (r.y - r.x + 1 > pyr_tile_max_src_rows()) ti.ok = false;
-      }
       ti.xr_off = (int)ranges.size(); ranges.insert(ranges.end(), xr.begin(), xr.end());
-      ti.yr_off = (int)ranges.size(); ranges.insert(ranges.end(), yr.begin(), yr.end());
+      for (int v = 0; v < 2; v++) {
+        const int TR = TRv[v];
+        ti.ngy[v] = (L.h + 2 * kEdge + TR - 1) / TR;
+        std::vector<int2> yr(ti.ngy[v], make_int2(1 << 30, -1));
+        for (int r = 0; r < L.h + 2 * kEdge; r++) {
+          const YTab& t = ytab[L.ytab_off + refl(r - kEdge, L.h)];
+          int2& q = yr[r / TR];
+          q.x = std::min(q.x, (int)std::min(t.sy0, t.sy1)); q.y = std::max(q.y, (int)std::max(t.sy0, t.sy1));
+        }
+        for (int2& r : yr) {
+          ti.src_rows[v] = std::max(ti.src_rows[v], r.y - r.x + 1);
+          if (r.y - r.x + 1 > pyr_tile_max_src_rows()) ti.ok = false;
+        }
+        ti.yr_off[v] = (int)ranges.size(); ranges.insert(ranges.end(), yr.begin(), yr.end());
+      }
       h->tile[l] = ti;
     }
     ORB_HIP_CHECK(hipMalloc(&h->d_xtp, sizeof(uint32_t) * std::max<size_t>(xtp.size(), 4)));
@@ -429,9 +439,12 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->gray, h->d_pyr, P, nframes, st);
   for (int l = 1; l < P.nlevels; l++) {
     const OrbExtractor::TileInfo& ti = h->tile[l];
-    if (ti.ok)
+    if (ti.ok) {
+      const int v = nframes <= kSmallBatchFrames ? 1 : 0;
       launch_pyr_resize_tile(h->d_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off, ti.ngx,
-                             h->d_ranges + ti.yr_off, ti.ngy, ti.src_rows, ti.src_pitch, nframes, st);
+                             h->d_ranges + ti.yr_off[v], ti.ngy[v], v ? pyr_tile_rows_small() : pyr_tile_rows(),
+                             ti.src_rows[v], ti.src_pitch, nframes, st);
+    }
     else
       launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
   }

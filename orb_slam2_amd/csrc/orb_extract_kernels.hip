@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ p
 // when the next output row starts on it.  xtp[] holds, per SLAB column, the source
 // column and the second tap's weight (first weight = 2048 - it; 0xFFFF marks columns
 // outside the 19-px frame, which are written as 0).
-constexpr int PR_TC = 1024, PR_TR = 16, PR_THREADS = 256;
+constexpr int PR_TC = 1024, PR_TR = 16, PR_TR_SMALL = 4, PR_THREADS = 256;  // tile height: batches / a few frames
 constexpr int PR_SROWS = 32, PR_MAXPITCH = 1536;  // limits of the staged source region
 
 __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __restrict__ pyr,
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
                                                                      LevelGeom Ld, const uint32_t* __restrict__ xtp,
                                                                      const YTab* __restrict__ yt,
                                                                      const int2* __restrict__ xrange,
-                                                                     const int2* __restrict__ yrange, int PR_SPITCH) {
+                                                                     const int2* __restrict__ yrange, int PR_SPITCH,
+                                                                     int tile_rows) {
   // staged source rows: the launch sizes this to the level's widest / tallest tile
   extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
   const int gx = blockIdx.z, gy = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
   uint32_t hprev[4] = {0, 0, 0, 0};
   int prev_row = -1;  // source row whose horizontal result is in hprev
   uint8_t* dst = pyr + (size_t)f * slab + Ld.off + c;
-  const int rend = min(gy * PR_TR + PR_TR, Ld.h + 2 * kEdge);
-  for (int r = gy * PR_TR; r < rend; r++) {
+  const int rend = min(gy * tile_rows + tile_rows, Ld.h + 2 * kEdge);
+  for (int r = gy * tile_rows; r < rend; r++) {
     const YTab ty = yt[refl101(r - kEdge, Ld.h)];
     const int s0 = ty.sy0, s1 = ty.sy1;
     uint32_t h0[4], h1[4];
@@ -1078,7 +1079,8 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 constexpr int D_THREADS = 256;
-constexpr int D_KPW = 4;  // keypoints per wavefront
+constexpr int D_KPW = 4;        // keypoints per wavefront (batches)
+constexpr int D_KPW_SMALL = 1;  // ... when a launch holds only a few frames: more, shorter wavefronts
 constexpr int D_RAW_ROWS = 32, D_BLR_ROWS = 48, D_PITCH = 64;  // staged rows (16 per load instruction), bytes per row
 constexpr int D_PAD = 16;                 // bytes in front of the level patch: its row 0 is read from offset -1
 
@@ -1135,6 +1137,7 @@ __device__ __forceinline__ Staged od_issue(const uint8_t* __restrict__ pyr, cons
   return s;
 }
 
+template <int KPW>
 __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* __restrict__ pyr,
                                                                 const uint8_t* __restrict__ blur,
                                                                 const uint32_t* __restrict__ sel_all,
@@ -1152,14 +1155,14 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   if (f >= nframes) return;
   const int chunk = slot - (slot / nchunks) * nchunks;
   const int lane = threadIdx.x & 63;
-  // A wavefront takes D_KPW consecutive slots of the per-frame selected array, so that the
+  // A wavefront takes KPW consecutive slots of the per-frame selected array, so that the
   // steering tables (constant per lane) are fetched once for all of them.
-  const int k0 = __builtin_amdgcn_readfirstlane((chunk * (D_THREADS / 64) + (int)(threadIdx.x >> 6)) * D_KPW);
+  const int k0 = __builtin_amdgcn_readfirstlane((chunk * (D_THREADS / 64) + (int)(threadIdx.x >> 6)) * KPW);
   if (k0 >= P.sel_total) return;
   // one round trip for everything needed to find the keypoints: the per-level counts
   // (lane l holds level l) and the selected records (lane j holds slot k0 + j)
   const int mycnt = lane < P.nlevels ? sel_cnt[f * P.nlevels + lane] : 0;
-  const uint32_t myv = (lane < D_KPW && k0 + lane < P.sel_total) ? sel_all[(size_t)f * P.sel_total + k0 + lane] : 0u;
+  const uint32_t myv = (lane < KPW && k0 + lane < P.sel_total) ? sel_all[(size_t)f * P.sel_total + k0 + lane] : 0u;
   float4 pat[4];  // pattern pairs lane + 64*j
 #pragma unroll
   for (int j = 0; j < 4; j++) pat[j] = d_patf[lane + 64 * j];
@@ -1175,7 +1178,7 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     Loc q;
     q.ok = false; q.l = 0; q.o = 0; q.cx = 0; q.cy = 0; q.pitch = 0; q.v = 0; q.lvl = 0;
     const int k = k0 + kk;
-    if (kk >= D_KPW || k >= P.sel_total) return q;
+    if (kk >= KPW || k >= P.sel_total) return q;
     q.v = __builtin_amdgcn_readlane(myv, kk);
     int l = 0, before = 0, tot = 0, cnt_l = 0;
 #pragma unroll
@@ -1203,7 +1206,7 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   Staged st;
   Loc cur = locate(0);
   if (cur.ok) st = od_issue(pyr, blur, cur.lvl, cur.cx, cur.pitch, rs, seg);
-  for (int kk = 0; kk < D_KPW; kk++) {
+  for (int kk = 0; kk < KPW; kk++) {
   const Loc nxt = locate(kk + 1);
   if (!cur.ok) {
     if (nxt.ok) st = od_issue(pyr, blur, nxt.lvl, nxt.cx, nxt.pitch, rs, seg);
@@ -1361,14 +1364,15 @@ void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, c
                      yt + Ld.ytab_off);
 }
 void launch_pyr_resize_tile(uint8_t* pyr, const Plan& P, int level, const uint32_t* xtp, const YTab* yt,
-                            const int2* xrange, int ngx, const int2* yrange, int ngy, int src_rows, int src_pitch,
-                            int nframes, hipStream_t st) {
+                            const int2* xrange, int ngx, const int2* yrange, int ngy, int tile_rows, int src_rows,
+                            int src_pitch, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(pyr_resize_tile_kernel, dim3(nframes, ngy, ngx), dim3(PR_THREADS), (size_t)src_rows * src_pitch, st,
                      pyr, P.slab, P.lv[level - 1], P.lv[level], xtp, yt + P.lv[level].ytab_off, xrange, yrange,
-                     src_pitch);
+                     src_pitch, tile_rows);
 }
 int pyr_tile_cols() { return PR_TC; }
 int pyr_tile_rows() { return PR_TR; }
+int pyr_tile_rows_small() { return PR_TR_SMALL; }
 int pyr_tile_max_src_rows() { return PR_SROWS; }
 int pyr_tile_max_src_bytes() { return PR_MAXPITCH; }
 void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, uint32_t* cand, int* cand_cnt,
@@ -1426,11 +1430,16 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurIte
 }
 void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel, const int* sel_cnt, const Plan& P,
                         OrbKeyPoint* kps, uint8_t* desc, int* n_out, int max_kp, int nframes, hipStream_t st) {
-  const int per_wg = (D_THREADS / 64) * D_KPW;
+  const bool small = nframes <= 8;
+  const int per_wg = (D_THREADS / 64) * (small ? D_KPW_SMALL : D_KPW);
   const int nb = (P.sel_total + per_wg - 1) / per_wg;
   const int groups = (nframes + 7) / 8;  // frames are dealt to the 8 XCDs in groups
-  hipLaunchKernelGGL(orient_desc_kernel, dim3((unsigned)groups * 8u * (unsigned)nb), dim3(D_THREADS), 0, st, pyr, blur, sel,
-                     sel_cnt, P, kps, desc, n_out, max_kp, nframes, nb);
+  if (small)
+    hipLaunchKernelGGL(orient_desc_kernel<D_KPW_SMALL>, dim3((unsigned)groups * 8u * (unsigned)nb), dim3(D_THREADS), 0, st,
+                       pyr, blur, sel, sel_cnt, P, kps, desc, n_out, max_kp, nframes, nb);
+  else
+    hipLaunchKernelGGL(orient_desc_kernel<D_KPW>, dim3((unsigned)groups * 8u * (unsigned)nb), dim3(D_THREADS), 0, st, pyr,
+                       blur, sel, sel_cnt, P, kps, desc, n_out, max_kp, nframes, nb);
 }
 
 int fast_use_width() { return F_USEW; }
