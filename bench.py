@@ -68,6 +68,12 @@ def main():
     ap.add_argument("--host-reps", type=int, default=5, help="repetitions of the host-buffer batch call (0 = skip)")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: libraries that print banners to file
+    # descriptor 1 (RCCL does when a communicator is created) are sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -356,7 +362,8 @@ def main():
             out.update(host)
         if parity:
             out.update(parity)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
