@@ -277,6 +277,7 @@ constexpr int F_MAXH = 66;    // tallest cell view (hCell <= 59, + 6)
 constexpr int F_MAXCELLS = 16;
 constexpr int F_QCAP = 64 + 256;  // a wave's queue: carried-over remainder + one row of survivors (re-queued entries while there is room)
 constexpr int F_CCAP = 512;       // corners kept per wavefront before falling back to a dense sweep
+constexpr int F_OVERFLOW = 1 << 20;  // a corner count that says: the list overflowed
 static_assert(3 + F_USEW + 6 <= 256, "a staged row must fit 64 lanes x 4 columns");
 
 typedef short fast_s2 __attribute__((ext_vector_type(2)));
@@ -294,14 +295,21 @@ __device__ __forceinline__ fast_s2 pk_max(fast_s2 a, fast_s2 b) { return __built
 // window wraps past p[15] the neighbour register is used with its halves exchanged.
 __device__ __forceinline__ fast_s2 swap2(fast_s2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 __device__ __forceinline__ int fast_v1(const uint8_t* p /* centre in LDS */, int t, bool dark_only, bool& again) {
-  const int c = p[0];
-  const int offs[16] = {3 * F_PITCH,      3 * F_PITCH + 1,  2 * F_PITCH + 2,  F_PITCH + 3,
-                        3,                -F_PITCH + 3,     -2 * F_PITCH + 2, -3 * F_PITCH + 1,
-                        -3 * F_PITCH,     -3 * F_PITCH - 1, -2 * F_PITCH - 2, -F_PITCH - 3,
-                        -3,               F_PITCH - 3,      2 * F_PITCH - 2,  3 * F_PITCH - 1};
+  // all seventeen reads relative to the ring's first byte in memory (p[9]), so that every offset
+  // is a non-negative constant that fits the LDS instruction's offset field: one address, no adds
+  constexpr int B = 3 * F_PITCH + 1;
+  typedef __attribute__((address_space(3))) const uint8_t* lds_bytes;
+  uint32_t ba = (uint32_t)(uintptr_t)(lds_bytes)p - B;
+  asm("" : "+v"(ba));  // opaque: otherwise the subtraction is folded back into seven negative offsets, an add each
+  const lds_bytes b = (lds_bytes)(uintptr_t)ba;
+  const int c = b[B];
+  const int offs[16] = {B + 3 * F_PITCH,     B + 3 * F_PITCH + 1, B + 2 * F_PITCH + 2, B + F_PITCH + 3,
+                        B + 3,               B - F_PITCH + 3,     B - 2 * F_PITCH + 2, B - 3 * F_PITCH + 1,
+                        B - 3 * F_PITCH,     B - 3 * F_PITCH - 1, B - 2 * F_PITCH - 2, B - F_PITCH - 3,
+                        B - 3,               B + F_PITCH - 3,     B + 2 * F_PITCH - 2, B + 3 * F_PITCH - 1};
   uint32_t r[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) r[k] = p[offs[k]];
+  for (int k = 0; k < 16; k++) r[k] = b[offs[k]];
   // which polarity can hold: an arc of 9 contains two adjacent compass points
   const bool br = (int)min(max(r[0], r[8]), max(r[4], r[12])) > c + t;
   const bool dk = (int)max(min(r[0], r[8]), min(r[4], r[12])) < c - t;
@@ -421,23 +429,27 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     return (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
   };
   unsigned cellmask = (1u << item.ncells) - 1;  // cells to (re)compute in this pass
+  // LDS byte address of this wave's queue (a scalar)
+  const uint32_t qbase = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&s_list[wave][0]);
+  // the same for its corner list and for the V map
+  const uint32_t cbase = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&s_corner[wave][0]);
+  const uint32_t vbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_v);
   for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? iniTh : minTh;
     int qn = 0;             // wave-uniform: entries waiting in this wave's queue
-    int ncorner = 0;        // wave-uniform: entries in this wave's corner list
-    bool overflow = false;  // wave-uniform: corner list too small, sweep densely
+    int ncorner = 0;        // wave-uniform: entries in this wave's corner list, or F_OVERFLOW: list too small, sweep densely
 
     // full test of queue entries [head, head + n) (n <= 64), corners appended
     auto drain = [&](int head, int n) {
       const int k = head + lane;
-      bool corner = false, again = false;
-      int e = 0;
+      bool again = false;
+      int e = 0, off = 0, v = 0;  // v = 0: no corner (idle lanes)
       if (lane < n) {
         e = s_list[wave][k];
-        const int off = e & 0x7FFF;
-        const int v = fast_v1(&s_img[off], t, (e & 0x8000) != 0, again);
-        corner = v > t;
-        if (corner) s_v[off] = (uint8_t)v;  // the V map starts at 0 (staging, or the clearing before pass 2)
+        off = e & 0x7FFF;
+        v = fast_v1(&s_img[off], t, (e & 0x8000) != 0, again);
       }
       // a pixel that either polarity could make a corner (rare) goes to the queue's tail once
       // more, marked (bit 15) for the darker ring
@@ -448,16 +460,43 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
           qn += __popcll(ma);
         } else if (again) {  // no room left in the queue: the second polarity right here
           bool unused;
-          const int off = e & 0x7FFF;
-          const int v = fast_v1(&s_img[off], t, true, unused);
-          if (v > t) { corner = true; s_v[off] = (uint8_t)v; }
+          v = max(v, fast_v1(&s_img[off], t, true, unused));
         }
       }
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);
-      const int nc = __popcll(m);
-      if (ncorner + nc > F_CCAP) overflow = true;
-      else if (corner) s_corner[wave][ncorner + below(m)] = (uint16_t)(e & 0x7FFF);
-      if (!overflow) ncorner += nc;
+      ncorner = __builtin_amdgcn_readfirstlane(ncorner);  // (the compiler does not see that it is the same in all lanes)
+      if (ncorner <= F_CCAP - 64) {
+        // corners (V > t): V into the map (which starts at 0: staging, or the clearing before the
+        // second pass) and the pixel's offset to the wave's corner list, both under exec = the
+        // corner mask and without a branch, as in the quick test's compaction
+        uint32_t caddr = cbase + 2u * (uint32_t)ncorner, tmp, tmp2;
+        unsigned long long save;
+        int cnt;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "v_cmp_lt_i32 vcc, %[t], %[v]\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "v_add_u32 %[tmp2], %[vbase], %[off]\n\t"
+            "v_mbcnt_lo_u32_b32 %[tmp], vcc_lo, 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[tmp], vcc_hi, %[tmp]\n\t"
+            "ds_write_b8 %[tmp2], %[v]\n\t"
+            "v_lshl_add_u32 %[tmp], %[tmp], 1, %[ca]\n\t"
+            "ds_write_b16 %[tmp], %[off]\n\t"
+            "s_mov_b64 exec, %[save]\n\t"
+            "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+            "s_lshl1_add_u32 %[ca], %[cnt], %[ca]\n\t"
+            : [ca] "+s"(caddr), [tmp] "=&v"(tmp), [tmp2] "=&v"(tmp2), [save] "=&s"(save), [cnt] "=&s"(cnt)
+            : [t] "v"(t), [v] "v"(v), [off] "v"(off), [vbase] "s"(vbase)
+            : "vcc", "scc", "memory");
+        ncorner = (int)((caddr - cbase) >> 1);
+      } else {  // the list is (nearly) full: the same with the room checked
+        const bool corner = v > t;
+        if (corner) s_v[off] = (uint8_t)v;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);
+        const int nc = __popcll(m);
+        if (ncorner + nc > F_CCAP) ncorner = F_OVERFLOW;
+        else if (corner) s_corner[wave][ncorner + below(m)] = (uint16_t)off;
+        if (ncorner != F_OVERFLOW) ncorner += nc;
+      }
     };
 
     // ---- V map for the masked cells, one run of adjacent masked cells at a time (the first
@@ -478,19 +517,29 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       const int rps = 64 >> lsh;  // rows per wavefront step
       const int li = lane & ((1 << lsh) - 1), sub = lane >> lsh;
       const int col4 = lc0 + 4 * li;
-      bool mine[4];
-      unsigned long long mine_mask[4];  // the same as wave masks
+      // per lane and pixel the threshold the quick test compares with: t, or 32767 for a pixel
+      // outside the run, which then never passes (two pixels per register, like the test values)
+      uint32_t tv[2];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int x = col4 + j - xoff;
-        mine[j] = li < nl && x >= x0 && x < x1;
-        mine_mask[j] = __builtin_amdgcn_ballot_w64(mine[j]);
+      for (int h2 = 0; h2 < 2; h2++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          const int x = col4 + 2 * h2 + jj - xoff;
+          const bool mine = li < nl && x >= x0 && x < x1;
+          w |= (uint32_t)(mine ? t : 32767) << (16 * jj);
+        }
+        tv[h2] = w;
       }
+      // byte offset of the lane's first pixel; a lane whose row lies below the view (the last step
+      // of a run with several rows per step) reads the last row and never passes
+      int rowoff_next = (wave * rps + sub + 3) * F_PITCH + col4;
+      const int rowoff_last = (hi - 1 + 3) * F_PITCH + col4;
       for (int yb = wave * rps; yb < hi; yb += (F_THREADS / 64) * rps) {
-        const int y = min(yb + sub, hi - 1);
-        const bool vy = yb + sub < hi;
-        const unsigned long long row_mask = __builtin_amdgcn_ballot_w64(vy);
-        const int rowoff = (y + 3) * F_PITCH + col4;  // byte offset of the lane's first pixel
+        const bool vy = rowoff_next <= rowoff_last;
+        const uint32_t tv01 = vy ? tv[0] : 0x7FFF7FFFu, tv23 = vy ? tv[1] : 0x7FFF7FFFu;
+        const int rowoff = min(rowoff_next, rowoff_last);
+        rowoff_next += (F_THREADS / 64) * rps * F_PITCH;
         const uint8_t* rowp = &s_img[rowoff];
         const uint32_t C = *reinterpret_cast<const uint32_t*>(rowp);
         const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4);
@@ -503,6 +552,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         //   max( min(max(p0,p8), max(p4,p12)) - c,  c - max(min(p0,p8), min(p4,p12)) ) > t.
         // Two pixels at a time on packed 16-bit lanes: v_perm spreads the bytes of the five dwords
         // (the pixels 3 to the left / right come straight out of the neighbouring dwords).
+        uint32_t dq[2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; h2++) {
           const uint32_t s01 = h2 ? 0x0c030c02u : 0x0c010c00u;
@@ -512,16 +562,39 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
           const fast_s2 p4 = as_s2(__builtin_amdgcn_perm(R, C, h2 ? 0x0c060c05u : 0x0c040c03u));    // pixels x+3
           const fast_s2 hiq = pk_min(pk_max(p0, p8), pk_max(p4, p12));
           const fast_s2 loq = pk_max(pk_min(p0, p8), pk_min(p4, p12));
-          const fast_s2 d = pk_max(hiq - c2, c2 - loq);
-#pragma unroll
-          for (int jj = 0; jj < 2; jj++) {
-            const int j = 2 * h2 + jj;
-            const bool pass = (jj ? d.y : d.x) > (short)t;
-            const bool ok = vy & mine[j] & pass;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass) & mine_mask[j] & row_mask;
-            if (ok) s_list[wave][qn + below(m)] = (uint16_t)(rowoff + j);
-            qn += __popcll(m);
-          }
+          dq[h2] = as_u32(pk_max(hiq - c2, c2 - loq));
+        }
+        // Compaction of the (up to) four passing pixels per lane into the wave's queue.  Written out
+        // by hand: per pixel one compare into vcc, the lane's rank among the passing lanes
+        // (v_mbcnt), one LDS write under exec = vcc and the queue's end moved on by the mask's
+        // population count - no branch (an LDS write with exec = 0 does nothing) and four scalar
+        // instructions, where the compiler's version of "if (pass) queue[n + rank] = x" takes a
+        // branch and eleven.
+        {
+          uint32_t qaddr = qbase + 2u * (uint32_t)qn, tmp, tmp2;
+          unsigned long long save;
+          int cnt;
+#define ORB_FAST_PUSH(TV, DQ, SEL, J)                                              \
+  "v_cmp_lt_i16_sdwa vcc, %[" TV "], %[" DQ "] src0_sel:" SEL " src1_sel:" SEL "\n\t" \
+  "s_mov_b64 exec, vcc\n\t"                                                       \
+  "v_add_u32 %[tmp2], " J ", %[val]\n\t"                                          \
+  "v_mbcnt_lo_u32_b32 %[tmp], vcc_lo, 0\n\t"                                      \
+  "v_mbcnt_hi_u32_b32 %[tmp], vcc_hi, %[tmp]\n\t"                                 \
+  "v_lshl_add_u32 %[tmp], %[tmp], 1, %[qa]\n\t"                                   \
+  "ds_write_b16 %[tmp], %[tmp2]\n\t"                                              \
+  "s_mov_b64 exec, %[save]\n\t"                                                   \
+  "s_bcnt1_i32_b64 %[cnt], vcc\n\t"                                               \
+  "s_lshl1_add_u32 %[qa], %[cnt], %[qa]\n\t"
+          asm volatile("s_mov_b64 %[save], exec\n\t"  //
+                       ORB_FAST_PUSH("tv01", "d01", "WORD_0", "0")  //
+                       ORB_FAST_PUSH("tv01", "d01", "WORD_1", "1")  //
+                       ORB_FAST_PUSH("tv23", "d23", "WORD_0", "2")  //
+                       ORB_FAST_PUSH("tv23", "d23", "WORD_1", "3")
+                       : [qa] "+s"(qaddr), [tmp] "=&v"(tmp), [tmp2] "=&v"(tmp2), [save] "=&s"(save), [cnt] "=&s"(cnt)
+                       : [tv01] "v"(tv01), [tv23] "v"(tv23), [d01] "v"(dq[0]), [d23] "v"(dq[1]), [val] "v"(rowoff)
+                       : "vcc", "scc", "memory");
+#undef ORB_FAST_PUSH
+          qn = (int)((qaddr - qbase) >> 1);
         }
         if (qn >= 64) {
           int head = 0;
@@ -538,7 +611,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       drain(head, n);
       head += n;
     }
-    if (lane == 0) s_ncorner[wave] = overflow ? -1 : ncorner;
+    if (lane == 0) s_ncorner[wave] = ncorner == F_OVERFLOW ? -1 : ncorner;
     __syncthreads();
     // ---- cell-local NMS over the corner lists; a corner that survives is counted for its cell
     // and written out at once (a cell that is computed again in the second pass has, by
