@@ -23,6 +23,7 @@ struct LevelGeom {
   int off;           // byte offset of the level's first (padded) row in the slab
   int nCols, nRows;  // FAST cell grid
   int wCell, hCell;
+  int wCellM;        // 65536 / wCell + 1: (n * wCellM) >> 16 == n / wCell for 0 <= n < 256
   int nValidCols, nValidRows;  // cells the reference does not skip
   int maxBX, maxBY;  // w - 16, h - 16
   int quota;         // keypoints wanted on this level

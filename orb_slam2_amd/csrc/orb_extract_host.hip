@@ -250,6 +250,7 @@ int build_plan(OrbExtractor* h, int rows, int cols, Plan& P, std::vector<XTab>& 
       return ORBHIP_ERR_UNSUPPORTED;
     }
     L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows);
+    L.wCellM = 65536 / std::max(1, L.wCell) + 1;
     if (L.hCell + 6 > fast_max_view_h() || L.wCell > fast_use_width()) {
       set_error("cell size out of range"); return ORBHIP_ERR_UNSUPPORTED;
     }

@@ -359,7 +359,9 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   // staged view and its V map: lds_rows rows each (the tallest cell view of the plan)
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   uint8_t* const s_img = s_dyn;
-  uint8_t* const s_v = s_dyn + lds_rows * F_PITCH;
+  // the V map is indexed like the view, but only its rows 2 .. th - 3 exist (corners lie in rows
+  // 3 .. th - 4, the suppression looks one row further): its first two rows would be the view's last two
+  uint8_t* const s_v = s_dyn + (lds_rows - 2) * F_PITCH;
   // per wavefront: quick-test survivors and corners (V > t), both as the pixel's byte offset in
   // the staged view (bit 15 of a survivor: test the darker ring only)
   __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const LevelGeom& L = P.lv[item.level];
   const int wCell = L.wCell, hCell = L.hCell;
-  const int wCellM = 65536 / wCell + 1;  // div_small(n, wCellM) = n / wCell
+  const int wCellM = L.wCellM;  // div_small(n, wCellM) = n / wCell
   const int iniY = kBorder + item.row * hCell;
   const int maxY = min(iniY + hCell + 6, L.maxBY);
   const int xb = kBorder + item.j0 * wCell;
@@ -403,11 +405,12 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       for (int k = 0; k < 4; k++) {
         const int r = r0 + k * (F_THREADS / 64);
         if (r < th) {
+          const bool vrow = r >= 2 && r < th - 2;
           *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * lane]) = v[k];
-          *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
+          if (vrow) *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
           if (lane < (F_PITCH - 256) / 4) {
             *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 256 + 4 * lane]) = 0;
-            *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 256 + 4 * lane]) = 0;
+            if (vrow) *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 256 + 4 * lane]) = 0;
           }
         }
       }
@@ -652,6 +655,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       __syncthreads();
       if (mycol) {
         int n = 0;
+#pragma unroll 1
         for (int y = 0; y < hi; y++) {
           const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + xoff];
           const int v = q[0];
@@ -664,6 +668,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       __syncthreads();
       if (mycol && s_total) {
         const int gbase = s_base;
+#pragma unroll 1
         for (int y = 0; y < hi; y++) {
           const int off = (y + 3) * F_PITCH + x + xoff;
           const uint8_t* q = &s_v[off];
@@ -678,6 +683,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     }
     if (pass == 1) break;
     unsigned need = 0;
+#pragma unroll 1
     for (int c = 0; c < item.ncells; c++)
       if (s_cnt[c] == 0) need |= 1u << c;
     if (need == 0) break;  // uniform
@@ -686,8 +692,10 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     // all suppressed, are dropped with the lists)
     {
       const int x = tid;
-      if (x < wi && ((need >> div_small(x, wCellM)) & 1u))
+      if (x < wi && ((need >> div_small(x, wCellM)) & 1u)) {
+#pragma unroll 1
         for (int y = 0; y < hi; y++) s_v[(y + 3) * F_PITCH + x + xoff] = 0;
+      }
     }
     __syncthreads();
   }
@@ -1453,7 +1461,7 @@ void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int n
   int rows = 7;
   for (int l = 0; l < P.nlevels; l++) rows = max(rows, P.lv[l].hCell + 6);
   rows = min(rows, F_MAXH);
-  hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), 2 * (size_t)rows * F_PITCH, st, pyr, P, items,
+  hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, P, items,
                      cand, cand_cnt, iniTh, minTh, rows);
 }
 template <int MAXS, int THREADS>
