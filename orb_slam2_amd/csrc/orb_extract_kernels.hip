@@ -393,26 +393,28 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   const int ndw = (xoff + 3 + wi + 3) >> 2;
   const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(iniY + kEdge) * L.pitch + a0;
   {
+    // all of this wave's rows are requested before the first one is waited for (one memory
+    // latency per workgroup, not one per four rows), and the V map is cleared in between
+    constexpr int W = F_THREADS / 64, NR = (F_MAXH + W - 1) / W;
     const int cc = min(lane, ndw - 1);
-    for (int r0 = wave; r0 < th; r0 += 4 * (F_THREADS / 64)) {
-      uint32_t v[4];
+    const uint8_t* src = base + (size_t)wave * L.pitch + 4 * cc;
+    uint32_t v[NR];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {  // issue the loads of four rows before the first LDS write
-        const int r = min(r0 + k * (F_THREADS / 64), th - 1);
-        v[k] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * L.pitch + 4 * cc);
-      }
+    for (int k = 0; k < NR; k++) {
+      v[k] = 0;
+      if (wave + k * W < th) v[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(k * W) * L.pitch);  // uniform
+    }
+#pragma unroll 1
+    for (int r = wave + 2; r < th - 2; r += W) {
+      *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
+      if (lane < (F_PITCH - 256) / 4) *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 256 + 4 * lane]) = 0;
+    }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int r = r0 + k * (F_THREADS / 64);
-        if (r < th) {
-          const bool vrow = r >= 2 && r < th - 2;
-          *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * lane]) = v[k];
-          if (vrow) *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
-          if (lane < (F_PITCH - 256) / 4) {
-            *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 256 + 4 * lane]) = 0;
-            if (vrow) *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 256 + 4 * lane]) = 0;
-          }
-        }
+    for (int k = 0; k < NR; k++) {
+      const int r = wave + k * W;
+      if (r < th) {
+        *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * lane]) = v[k];
+        if (lane < (F_PITCH - 256) / 4) *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 256 + 4 * lane]) = 0;
       }
     }
   }
