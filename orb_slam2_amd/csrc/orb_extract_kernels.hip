@@ -620,13 +620,16 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     __syncthreads();
     // ---- cell-local NMS over the corner lists; a corner that survives is counted for its cell
     // and written out at once (a cell that is computed again in the second pass has, by
-    // definition, no survivor in the first).  Each wavefront reserves room for the survivors
-    // of 64 corners with one atomic of its own; the order within a level's list is arbitrary,
-    // the quad-tree kernel does not depend on it.
+    // definition, no survivor in the first).  The survivors are first moved to the front of the
+    // wave's list (in place: an entry is read before any lane can overwrite it), then the wave
+    // reserves their room with ONE atomic and writes them; a wave waits for the atomic's return
+    // once, not once per 64 corners.  The order within a level's list is arbitrary, the
+    // quad-tree kernel does not depend on it.
     bool any_overflow = false;
 #pragma unroll
     for (int w = 0; w < F_THREADS / 64; w++) any_overflow |= s_ncorner[w] < 0;
     if (!any_overflow) {
+      int nkeep = 0;                              // uniform
       for (int k0 = 0; k0 < ncorner; k0 += 64) {  // uniform
         const int k = k0 + lane;
         const int off = k < ncorner ? (int)s_corner[wave][k] : 3 * F_PITCH + 4;
@@ -638,12 +641,19 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         const bool keep = k < ncorner && v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1);
         if (keep) atomicAdd(&s_cnt[ecj], 1);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (m) {
-          int wbase = 0;
-          if (lane == 0) wbase = atomicAdd(out_cnt, __popcll(m));
-          wbase = __builtin_amdgcn_readfirstlane(wbase);
-          const int slot = wbase + below(m);
-          if (keep && slot < L.cand_cap) out[slot] = record(off, ey, v);
+        if (keep) s_corner[wave][nkeep + below(m)] = (uint16_t)off;
+        nkeep += __popcll(m);
+      }
+      if (nkeep) {
+        int wbase = 0;
+        if (lane == 0) wbase = atomicAdd(out_cnt, nkeep);
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        for (int k0 = 0; k0 < nkeep; k0 += 64) {
+          const int k = k0 + lane;
+          if (k < nkeep && wbase + k < L.cand_cap) {
+            const int off = s_corner[wave][k];
+            out[wbase + k] = record(off, div_pitch(off), s_v[off]);
+          }
         }
       }
       __syncthreads();
