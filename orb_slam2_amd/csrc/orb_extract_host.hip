@@ -18,7 +18,8 @@ namespace orbhip {
 void launch_pyr_level0(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, int, hipStream_t);
 void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, const int*, uint8_t*, const Plan&, int, hipStream_t);
 void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
-void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, uint32_t*, int*, int, int, int, hipStream_t);
+void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, int, uint32_t*, int*, int, int, int, hipStream_t);
+int fast_rows_dense();
 hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, int, hipStream_t);
 void launch_blur(const uint8_t*, uint8_t*, const Plan&, const BlurItem*, int, const int*, int, hipStream_t);
 hipError_t upload_orient_tables();
@@ -145,6 +146,7 @@ struct OrbExtractor {
   uint32_t* d_xtp = nullptr;
   int2* d_ranges = nullptr;
   std::vector<FastItem> fast_items;
+  int fast_items_short = 0;  // the first so many items have views of at most fast_rows_dense() rows
   std::vector<BlurItem> blur_items;
   // device buffers
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
@@ -326,6 +328,11 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   Plan P; std::vector<XTab> xtab; std::vector<YTab> ytab; std::vector<FastItem> fi; std::vector<BlurItem> bi;
   int rc = build_plan(h, rows, cols, P, xtab, ytab, fi, bi);
   if (rc != ORBHIP_OK) return rc;
+  // FAST items of levels whose cell views are short enough for one more workgroup per CU go first:
+  // they are launched with the smaller LDS footprint, the others after them
+  const int dense_rows = fast_rows_dense();
+  const size_t n_short = std::stable_partition(fi.begin(), fi.end(), [&](const FastItem& it) {
+                           return P.lv[it.level].hCell + 6 <= dense_rows; }) - fi.begin();
   ORB_HIP_CHECK(hipDeviceSynchronize());
   const int cap = std::max(nframes, (h->have_plan && h->plan.rows == rows && h->plan.cols == cols) ? h->cap_frames : 0);
   free_plan_buffers(h);
@@ -413,6 +420,7 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   ORB_HIP_CHECK(hipMemsetAsync(h->d_sel_cnt, 0, sizeof(int) * (size_t)P.nlevels * cap, h->stream));
   ORB_HIP_CHECK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
   h->plan = P; h->fast_items = fi; h->blur_items = bi;
+  h->fast_items_short = (int)n_short;
   h->ot_slots = 0;
   for (int l = 0; l < P.nlevels; l++)
     h->ot_slots = std::max(h->ot_slots, std::max(P.lv[l].quota + 3, 4 * P.lv[l].nIni) + P.lv[l].nIni + 8);
@@ -450,7 +458,7 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
       launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[1], st));
-  launch_fast(h->d_pyr, P, h->d_fast_items, (int)h->fast_items.size(), h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
+  launch_fast(h->d_pyr, P, h->d_fast_items, (int)h->fast_items.size(), nframes <= kSmallBatchFrames ? 0 : h->fast_items_short, h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
               nframes, st);
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));
   ORB_HIP_CHECK(launch_octree(h->d_cand, h->d_cand_cnt, h->d_pnode, h->d_sel, h->d_sel_cnt, P, h->ot_slots, nframes, st));

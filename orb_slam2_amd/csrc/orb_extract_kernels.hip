@@ -272,7 +272,8 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
 // ---------------------------------------------------------------------------
 constexpr int F_THREADS = 256;
 constexpr int F_USEW = 240;   // widest run of cell interiors per workgroup
-constexpr int F_PITCH = 272;  // LDS row pitch; a wavefront's 64 lanes x 4 columns cover a staged row
+constexpr int F_PITCH = 256;  // LDS row pitch: a wavefront's 64 lanes x 4 columns are a staged row (the dwords left and right of
+                              // a row that the quick test reads belong to the rows above and below: never a pixel of the run)
 constexpr int F_MAXH = 66;    // tallest cell view (hCell <= 59, + 6)
 constexpr int F_MAXCELLS = 16;
 constexpr int F_QCAP = 64 + 256;  // a wave's queue: carried-over remainder + one row of survivors (re-queued entries while there is room)
@@ -345,10 +346,10 @@ __device__ __forceinline__ bool fast_nms_keep(const uint8_t* q, int v, bool hasL
   return v > max(mc, max(ml, mr));
 }
 
-// Exact floor(off / F_PITCH) for off < 32768 and floor(n / d) for n, d < 256 with m = 65536 / d + 1,
-// by multiplication (checked exhaustively on the host side of the tests).
-static_assert(F_PITCH == 272, "div_pitch's constant is for a pitch of 272");
-__device__ __forceinline__ int div_pitch(int off) { return (int)(((uint32_t)off * 61681u) >> 24); }
+// floor(off / F_PITCH), and floor(n / d) for n, d < 256 with m = 65536 / d + 1 by multiplication
+// (checked exhaustively on the host side of the tests).
+static_assert(F_PITCH == 256, "div_pitch shifts by 8");
+__device__ __forceinline__ int div_pitch(int off) { return off >> 8; }
 __device__ __forceinline__ int div_small(int n, int m) { return (n * m) >> 16; }
 
 __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
@@ -407,14 +408,12 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
 #pragma unroll 1
     for (int r = wave + 2; r < th - 2; r += W) {
       *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
-      if (lane < (F_PITCH - 256) / 4) *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 256 + 4 * lane]) = 0;
     }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
       const int r = wave + k * W;
       if (r < th) {
         *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * lane]) = v[k];
-        if (lane < (F_PITCH - 256) / 4) *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 256 + 4 * lane]) = 0;
       }
     }
   }
@@ -1468,13 +1467,36 @@ int pyr_tile_rows() { return PR_TR; }
 int pyr_tile_rows_small() { return PR_TR_SMALL; }
 int pyr_tile_max_src_rows() { return PR_SROWS; }
 int pyr_tile_max_src_bytes() { return PR_MAXPITCH; }
-void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, uint32_t* cand, int* cand_cnt,
-                 int iniTh, int minTh, int nframes, hipStream_t st) {
+// The tallest cell view with which six workgroups of fast_kernel fit a CU's LDS (160 KB, handed
+// out in 512-byte units on gfx950; five fit with the tallest view the kernel takes, and the sixth
+// is worth a tenth of the kernel's time).
+int fast_rows_dense() {
+  static const int rows = [] {
+    hipFuncAttributes a{};
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(fast_kernel)) != hipSuccess) return 0;
+    const long budget = (160 * 1024 / 6) / 512 * 512 - (long)a.sharedSizeBytes;  // dynamic LDS a workgroup may take
+    const long r = (budget / F_PITCH + 4) / 2;
+    return budget < 10 * F_PITCH ? 0 : (int)(r < F_MAXH ? r : F_MAXH);
+  }();
+  return rows;
+}
+// items [0, nshort) have views of at most fast_rows_dense() rows (one launch with that LDS footprint),
+// the others follow in a launch sized for the tallest view; nshort = 0: one launch for all
+void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, int nshort, uint32_t* cand,
+                 int* cand_cnt, int iniTh, int minTh, int nframes, hipStream_t st) {
   int rows = 7;
   for (int l = 0; l < P.nlevels; l++) rows = max(rows, P.lv[l].hCell + 6);
   rows = min(rows, F_MAXH);
-  hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, P, items,
-                     cand, cand_cnt, iniTh, minTh, rows);
+  if (nshort > 0 && rows > fast_rows_dense()) {
+    const int r = fast_rows_dense();
+    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nshort), dim3(F_THREADS), (2 * (size_t)r - 4) * F_PITCH, st, pyr, P, items,
+                       cand, cand_cnt, iniTh, minTh, r);
+    items += nshort;
+    nitems -= nshort;
+  }
+  if (nitems > 0)
+    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, P, items,
+                       cand, cand_cnt, iniTh, minTh, rows);
 }
 template <int MAXS, int THREADS>
 static hipError_t launch_octree_t(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel,
