@@ -540,16 +540,24 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       int rowoff_next = (wave * rps + sub + 3) * F_PITCH + col4;
       const int rowoff_last = (hi - 1 + 3) * F_PITCH + col4;
       for (int yb = wave * rps; yb < hi; yb += (F_THREADS / 64) * rps) {
-        const bool vy = rowoff_next <= rowoff_last;
-        const uint32_t tv01 = vy ? tv[0] : 0x7FFF7FFFu, tv23 = vy ? tv[1] : 0x7FFF7FFFu;
-        const int rowoff = min(rowoff_next, rowoff_last);
+        if (yb + rps > hi) {  // uniform, and only in the last step of a run with several rows per step
+          asm volatile("");   // (keeps this a branch: as selects it would cost every step four instructions)
+          if (rowoff_next > rowoff_last) { rowoff_next = rowoff_last; tv[0] = tv[1] = 0x7FFF7FFFu; }
+        }
+        const uint32_t tv01 = tv[0], tv23 = tv[1];
+        const int rowoff = rowoff_next;
         rowoff_next += (F_THREADS / 64) * rps * F_PITCH;
-        const uint8_t* rowp = &s_img[rowoff];
-        const uint32_t C = *reinterpret_cast<const uint32_t*>(rowp);
-        const uint32_t Lw = *reinterpret_cast<const uint32_t*>(rowp - 4);
-        const uint32_t R = *reinterpret_cast<const uint32_t*>(rowp + 4);
-        const uint32_t U = *reinterpret_cast<const uint32_t*>(rowp - 3 * F_PITCH);
-        const uint32_t D = *reinterpret_cast<const uint32_t*>(rowp + 3 * F_PITCH);
+        // the five dwords around the lane's pixels, addressed from the topmost one (offsets that
+        // fit the LDS instructions' offset fields; opaque, or the compiler re-bases them with adds)
+        typedef __attribute__((address_space(3))) const uint32_t* lds_words;
+        uint32_t ra = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)s_img + rowoff - 3 * F_PITCH;
+        asm("" : "+v"(ra));
+        const lds_words rw = (lds_words)(uintptr_t)ra;
+        const uint32_t U = rw[0];
+        const uint32_t Lw = rw[3 * F_PITCH / 4 - 1];
+        const uint32_t C = rw[3 * F_PITCH / 4];
+        const uint32_t R = rw[3 * F_PITCH / 4 + 1];
+        const uint32_t D = rw[6 * F_PITCH / 4];
         // per pixel: some ring pixel pair at the compass points is brighter / darker than the centre
         // by more than t.  Nine contiguous ring pixels always contain two adjacent compass points:
         // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12), for "brighter" as for "darker", i.e.
@@ -578,22 +586,22 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
           uint32_t qaddr = qbase + 2u * (uint32_t)qn, tmp, tmp2;
           unsigned long long save;
           int cnt;
-#define ORB_FAST_PUSH(TV, DQ, SEL, J)                                              \
+#define ORB_FAST_PUSH(TV, DQ, SEL, VAL_INSTR, VAL)                                  \
   "v_cmp_lt_i16_sdwa vcc, %[" TV "], %[" DQ "] src0_sel:" SEL " src1_sel:" SEL "\n\t" \
   "s_mov_b64 exec, vcc\n\t"                                                       \
-  "v_add_u32 %[tmp2], " J ", %[val]\n\t"                                          \
+  VAL_INSTR                                                                        \
   "v_mbcnt_lo_u32_b32 %[tmp], vcc_lo, 0\n\t"                                      \
   "v_mbcnt_hi_u32_b32 %[tmp], vcc_hi, %[tmp]\n\t"                                 \
   "v_lshl_add_u32 %[tmp], %[tmp], 1, %[qa]\n\t"                                   \
-  "ds_write_b16 %[tmp], %[tmp2]\n\t"                                              \
+  "ds_write_b16 %[tmp], %[" VAL "]\n\t"                                           \
   "s_mov_b64 exec, %[save]\n\t"                                                   \
   "s_bcnt1_i32_b64 %[cnt], vcc\n\t"                                               \
   "s_lshl1_add_u32 %[qa], %[cnt], %[qa]\n\t"
           asm volatile("s_mov_b64 %[save], exec\n\t"  //
-                       ORB_FAST_PUSH("tv01", "d01", "WORD_0", "0")  //
-                       ORB_FAST_PUSH("tv01", "d01", "WORD_1", "1")  //
-                       ORB_FAST_PUSH("tv23", "d23", "WORD_0", "2")  //
-                       ORB_FAST_PUSH("tv23", "d23", "WORD_1", "3")
+                       ORB_FAST_PUSH("tv01", "d01", "WORD_0", "", "val")  //
+                       ORB_FAST_PUSH("tv01", "d01", "WORD_1", "v_add_u32 %[tmp2], 1, %[val]\n\t", "tmp2")  //
+                       ORB_FAST_PUSH("tv23", "d23", "WORD_0", "v_add_u32 %[tmp2], 2, %[val]\n\t", "tmp2")  //
+                       ORB_FAST_PUSH("tv23", "d23", "WORD_1", "v_add_u32 %[tmp2], 3, %[val]\n\t", "tmp2")
                        : [qa] "+s"(qaddr), [tmp] "=&v"(tmp), [tmp2] "=&v"(tmp2), [save] "=&s"(save), [cnt] "=&s"(cnt)
                        : [tv01] "v"(tv01), [tv23] "v"(tv23), [d01] "v"(dq[0]), [d23] "v"(dq[1]), [val] "v"(rowoff)
                        : "vcc", "scc", "memory");
