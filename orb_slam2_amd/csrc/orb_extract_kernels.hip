@@ -24,17 +24,23 @@ __device__ __forceinline__ int refl101(int i, int n) {
 // (reference src/ORBextractor.cc:1406-1408).  One thread writes 16 consecutive bytes of
 // a padded slab row.  Input rows have any alignment (the stride need not be a multiple
 // of 4), so interior pieces are read as five aligned dwords and shifted into place;
-// pieces that touch the frame or the row ends go byte by byte.
+// pieces that touch the frame or the row ends go byte by byte.  The interior pieces are
+// numbered first (row by row), the others after them, so that all but one wavefront hold a
+// single kind and none runs both paths.
 // ---------------------------------------------------------------------------
 constexpr int L0_PIECES = 2;  // 16-byte pieces per thread of the level-0 copy
+struct L0Map {
+  int ca, ni;      // pieces [ca, ca + ni) of a row are interior (ni = 0: none)
+  int nb;          // the other pieces of a row
+  uint32_t ni_m, nb_m;  // 2^32 / n + 1: t / n == umulhi(t, m) for t * n < 2^32
+  int n_int, total;     // interior pieces, all pieces (of one frame)
+};
 __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restrict__ img, size_t stride,
                                                          size_t frame_stride, uint8_t* __restrict__ pyr,
-                                                         unsigned long long slab, LevelGeom L) {
+                                                         unsigned long long slab, LevelGeom L, L0Map M) {
   // a thread moves L0_PIECES pieces a fixed distance apart; all their loads are issued before
   // the first result is needed, so that more bytes are in flight per wavefront
-  const int nchunk = L.pitch >> 4;
-  const int total = nchunk * (L.h + 2 * kEdge);
-  const int half = (total + L0_PIECES - 1) / L0_PIECES;
+  const int half = (M.total + L0_PIECES - 1) / L0_PIECES;
   const int t0 = blockIdx.y * 256 + threadIdx.x;
   if (t0 >= half) return;
   const int f = blockIdx.x;
@@ -46,14 +52,23 @@ __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restri
 #pragma unroll
   for (int u = 0; u < L0_PIECES; u++) {
     const int t = t0 + u * half;
-    live[u] = t < total;
+    live[u] = t < M.total;
     const int tt = live[u] ? t : 0;
-    row[u] = tt / nchunk;  // padded row
-    c16[u] = (tt - row[u] * nchunk) * 16;
+    fastp[u] = tt < M.n_int;
+    int c;
+    if (fastp[u]) {
+      row[u] = (int)__umulhi((uint32_t)tt, M.ni_m);
+      c = M.ca + tt - row[u] * M.ni;
+    } else {
+      const int v = tt - M.n_int;
+      row[u] = (int)__umulhi((uint32_t)v, M.nb_m);
+      const int j = v - row[u] * M.nb;
+      c = j < M.ca ? j : j + M.ni;
+    }
+    c16[u] = c * 16;
     const int iy = refl101(row[u] - kEdge, L.h);
     S[u] = img + (size_t)f * frame_stride + (size_t)iy * stride;
     px0[u] = c16[u] - kXOff;
-    fastp[u] = px0[u] >= 4 && px0[u] + 20 <= L.w;
     if (fastp[u]) {
       const uintptr_t a = reinterpret_cast<uintptr_t>(S[u] + px0[u]);
       const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ p
 // when the next output row starts on it.  xtp[] holds, per SLAB column, the source
 // column and the second tap's weight (first weight = 2048 - it; 0xFFFF marks columns
 // outside the 19-px frame, which are written as 0).
-constexpr int PR_TC = 1024, PR_TR = 16, PR_TR_SMALL = 4, PR_THREADS = 256;  // tile height: batches / a few frames
+constexpr int PR_TC = 1024, PR_TR = 8, PR_TR_SMALL = 4, PR_THREADS = 256;  // tile height: batches / a few frames (6 to 10 rows measure the same, 16 and 4 are 3 % slower)
 constexpr int PR_SROWS = 32, PR_MAXPITCH = 1536;  // limits of the staged source region
 
 __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __restrict__ pyr,
@@ -1436,10 +1451,20 @@ hipError_t upload_orient_tables() {
 void launch_pyr_level0(const uint8_t* img, size_t stride, size_t frame_stride, uint8_t* pyr, const Plan& P,
                        int nframes, hipStream_t st) {
   const LevelGeom& L = P.lv[0];
-  const int pieces = (L.pitch / 16) * (L.h + 2 * kEdge);
-  const int per_thread = (pieces + L0_PIECES - 1) / L0_PIECES;
+  const int nchunk = L.pitch / 16, nrows = L.h + 2 * kEdge;
+  // interior pieces: 16 c - kXOff >= 4 and 16 c - kXOff + 20 <= w
+  L0Map M{};
+  M.ca = (kXOff + 4 + 15) / 16;
+  const int cb = (L.w + kXOff - 20) / 16 + 1;
+  M.ni = cb - M.ca >= 2 ? cb - M.ca : 0;
+  M.nb = nchunk - M.ni;
+  M.ni_m = M.ni ? (uint32_t)((1ull << 32) / (unsigned)M.ni + 1) : 0;
+  M.nb_m = (uint32_t)((1ull << 32) / (unsigned)M.nb + 1);
+  M.n_int = M.ni * nrows;
+  M.total = nchunk * nrows;
+  const int per_thread = (M.total + L0_PIECES - 1) / L0_PIECES;
   dim3 grid(nframes, (per_thread + 255) / 256);
-  hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L);
+  hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, M);
 }
 void launch_pyr_level0_color(const uint8_t* img, size_t stride, size_t frame_stride, int channels, bool rgb_order,
                              const int* gray /* weight R, G, B, shift */, uint8_t* pyr, const Plan& P, int nframes,

@@ -271,6 +271,25 @@ def test_large_batch_equals_small_batches(oracle):
         check_against(bk[f], bd[f], rk, rd)
 
 
+@pytest.mark.parametrize("rows,cols,nlevels,scale", [(376, 1241, 8, 1.2), (480, 640, 8, 1.2), (211, 333, 5, 1.3),
+                                                    (1080, 1920, 8, 1.2)])
+def test_batch_stages_match_oracle(oracle, rows, cols, nlevels, scale):
+    """Batches of more than 8 frames take their own launches (taller resize tiles, FAST in two
+    launches by view height, four keypoints per wavefront): every stage of every level of a
+    few frames of such a batch against the oracle, pixel for pixel."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd.synth import synth_sequence
+    n = 11
+    seq = synth_sequence(rows, cols, n, seed=23, step=3)
+    ex = ORBextractor(1000, scale, nlevels, 20, 7)
+    bk, bd = ex.extract_batch(seq)
+    ref = oracle.Extractor(1000, scale, nlevels, 20, 7)
+    for f in (0, 6, 10):
+        rk, rd = ref(seq[f])
+        check_against(bk[f], bd[f], rk, rd)
+        check_stages(ex, ref, nlevels, frame=f)
+
+
 def _colour_image(rows, cols, ch, seed):
     """A colour image whose grey value has corners: the synthetic grey scene modulated per
     channel, plus noise, so that the three weights all matter."""
