@@ -47,11 +47,13 @@ __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restri
   uint32_t x[L0_PIECES][5];
   const uint8_t* S[L0_PIECES];
   int px0[L0_PIECES], row[L0_PIECES], c16[L0_PIECES];
-  bool live[L0_PIECES], fastp[L0_PIECES];
+  bool live[L0_PIECES], fastp[L0_PIECES], own[L0_PIECES];
   uint32_t sh[L0_PIECES];
 #pragma unroll
   for (int u = 0; u < L0_PIECES; u++) {
     const int t = t0 + u * half;
+    own[u] = false;
+    x[u][0] = 0;
     live[u] = t < M.total;
     const int tt = live[u] ? t : 0;
     fastp[u] = tt < M.n_int;
@@ -70,12 +72,23 @@ __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restri
     S[u] = img + (size_t)f * frame_stride + (size_t)iy * stride;
     px0[u] = c16[u] - kXOff;
     if (fastp[u]) {
+      // four dwords in one load (any dword alignment); the fifth is the next lane's first when
+      // that lane holds the next piece of the same row, and a load of its own otherwise
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
       const uintptr_t a = reinterpret_cast<uintptr_t>(S[u] + px0[u]);
       const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
       sh[u] = (uint32_t)(a & 3);
-#pragma unroll
-      for (int k = 0; k < 5; k++) x[u][k] = q[k];
+      const u32x4 X = *reinterpret_cast<const u32x4*>(q);
+      x[u][0] = X.x; x[u][1] = X.y; x[u][2] = X.z; x[u][3] = X.w;
+      own[u] = (threadIdx.x & 63) == 63 || c + 1 >= M.ca + M.ni || t0 + 1 >= half;  // (the next lane may have left)
+      x[u][4] = 0;
+      if (own[u]) x[u][4] = q[4];
     }
+  }
+#pragma unroll
+  for (int u = 0; u < L0_PIECES; u++) {  // (all lanes of the wavefront take part in the exchange)
+    const uint32_t nxt = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((threadIdx.x & 63) + 1), (int)x[u][0]);
+    if (fastp[u] && !own[u]) x[u][4] = nxt;
   }
 #pragma unroll
   for (int u = 0; u < L0_PIECES; u++) {
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ p
 // outside the 19-px frame, which are written as 0).
 constexpr int PR_TC = 1024, PR_TR = 8, PR_TR_SMALL = 4, PR_THREADS = 256;  // tile height: batches / a few frames (6 to 10 rows measure the same, 16 and 4 are 3 % slower)
 constexpr int PR_SROWS = 32, PR_MAXPITCH = 1536;  // limits of the staged source region
+static_assert(sizeof(YTab) == 8, "a row's vertical taps are fetched as one 64-bit word");
 
 __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __restrict__ pyr,
                                                                      unsigned long long slab, LevelGeom Ls,
@@ -217,6 +231,12 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
     for (int c = tid & 63; c < n16; c += 64)
       *reinterpret_cast<uint4*>(&s_src[r * PR_SPITCH + 16 * c]) =
           *reinterpret_cast<const uint4*>(src + (size_t)r * Ls.pitch + 16 * c);
+  // the rows' vertical taps: lane i of every wavefront fetches those of the tile's row i now (the
+  // loop below reads them with v_readlane instead of waiting for a scalar load per row)
+  const int rbeg = gy * tile_rows;
+  unsigned long long ytl = 0;
+  if ((tid & 63) < tile_rows)
+    ytl = *reinterpret_cast<const unsigned long long*>(&yt[refl101(min(rbeg + (tid & 63), Ld.h + 2 * kEdge - 1) - kEdge, Ld.h)]);
   __syncthreads();
   const int c = gx * PR_TC + 4 * tid;
   if (c >= Ld.pitch) return;
@@ -242,8 +262,11 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
   int prev_row = -1;  // source row whose horizontal result is in hprev
   uint8_t* dst = pyr + (size_t)f * slab + Ld.off + c;
   const int rend = min(gy * tile_rows + tile_rows, Ld.h + 2 * kEdge);
-  for (int r = gy * tile_rows; r < rend; r++) {
-    const YTab ty = yt[refl101(r - kEdge, Ld.h)];
+  for (int r = rbeg; r < rend; r++) {
+    const uint32_t ylo = __builtin_amdgcn_readlane((uint32_t)ytl, r - rbeg);
+    const uint32_t yhi = __builtin_amdgcn_readlane((uint32_t)(ytl >> 32), r - rbeg);
+    YTab ty;
+    ty.sy0 = (uint16_t)ylo; ty.sy1 = (uint16_t)(ylo >> 16); ty.b0 = (int16_t)yhi; ty.b1 = (int16_t)(yhi >> 16);
     const int s0 = ty.sy0, s1 = ty.sy1;
     uint32_t h0[4], h1[4];
     if (s0 == prev_row) {
