@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_kernel(const uint32_t* __re
 // and sum to 256; the row pass keeps 8.8, the column pass 16.16, result
 // (acc + 2^15) >> 16.  The padded pyramid already holds the reflected border.
 // ---------------------------------------------------------------------------
-constexpr int B_TW = 128, B_TH = 32, B_THREADS = 256;
+constexpr int B_TW = 128, B_TH = 48, B_THREADS = 256;
 constexpr int B_ROWS = B_TH + 6;  // staged rows: 3 above, 3 below
 constexpr int B_INP = 160;        // staged bytes per row: level x0-16 .. x0+143
 
@@ -1126,10 +1126,10 @@ __global__ __launch_bounds__(B_THREADS) void blur_kernel(const uint8_t* __restri
                                                          int fchunk, int nframes, int t0, int t1, int t2, int t3) {
   __shared__ __attribute__((aligned(16))) uint8_t s_in[B_ROWS * B_INP];
   __shared__ __attribute__((aligned(16))) uint32_t s_hp[(B_ROWS / 2) * B_TW];  // h[2p][x] | h[2p+1][x] << 16
-  // grid.x = the frames of one chunk, grid.y = tile x chunk: all tiles of a chunk of frames are
-  // dispatched before the next chunk starts (see launch_blur)
-  const BlurItem it = items[blockIdx.y % nitems];
-  const int f = (blockIdx.y / nitems) * fchunk + blockIdx.x, tid = threadIdx.x;
+  // grid.x = the frames of one chunk, grid.y = tile, grid.z = chunk: all tiles of a chunk of
+  // frames are dispatched before the next chunk starts (see launch_blur)
+  const BlurItem it = items[blockIdx.y];
+  const int f = blockIdx.z * fchunk + blockIdx.x, tid = threadIdx.x;
   if (f >= nframes) return;
   const LevelGeom& L = P.lv[it.level];
   const int x0 = it.tx * B_TW, y0 = it.ty * B_TH;
@@ -1589,14 +1589,14 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurIte
   // Large batches are therefore dispatched 8 frames (one per XCD) at a time.  The other kernels
   // gain nothing from it, and FAST loses: its items are ordered longest first over the batch.
   int fchunk = nframes > 128 ? 8 : nframes;
-  while ((long long)nitems * ((nframes + fchunk - 1) / fchunk) > 65535) fchunk *= 2;  // grid.y limit
+  while ((nframes + fchunk - 1) / fchunk > 65535) fchunk *= 2;  // grid.z limit
   fchunk = min(fchunk, nframes);
   const int nchunks = (nframes + fchunk - 1) / fchunk;
   if (taps[3] + 2 * (taps[0] + taps[1] + taps[2]) > 256)
-    hipLaunchKernelGGL(blur_kernel<true>, dim3(fchunk, nitems * nchunks), dim3(B_THREADS), 0, st, pyr, blur, P, items,
+    hipLaunchKernelGGL(blur_kernel<true>, dim3(fchunk, nitems, nchunks), dim3(B_THREADS), 0, st, pyr, blur, P, items,
                        nitems, fchunk, nframes, taps[0], taps[1], taps[2], taps[3]);
   else
-    hipLaunchKernelGGL(blur_kernel<false>, dim3(fchunk, nitems * nchunks), dim3(B_THREADS), 0, st, pyr, blur, P, items,
+    hipLaunchKernelGGL(blur_kernel<false>, dim3(fchunk, nitems, nchunks), dim3(B_THREADS), 0, st, pyr, blur, P, items,
                        nitems, fchunk, nframes, taps[0], taps[1], taps[2], taps[3]);
 }
 void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel, const int* sel_cnt, const Plan& P,
