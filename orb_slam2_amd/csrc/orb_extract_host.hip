@@ -147,6 +147,7 @@ struct OrbExtractor {
   int2* d_ranges = nullptr;
   std::vector<FastItem> fast_items;
   int fast_items_short = 0;  // the first so many items have views of at most fast_rows_dense() rows
+  int fast_items_few = 0;    // items [size - fast_items_few, size) are the same cells cut for launches of a few frames
   std::vector<BlurItem> blur_items;
   // device buffers
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
@@ -190,6 +191,7 @@ struct OrbExtractor {
 namespace {
 
 constexpr int kSmallBatchFrames = 8;               // up to this many frames a launch is cut into more, smaller workgroups
+constexpr int kFewFrames = 4;                       // up to this many frames FAST takes shorter runs of cells
 constexpr int kGraphMaxFrames = 8;                 // batches up to this size replay a captured graph
 constexpr int kPoolThreads = 8;                    // host threads that pack a large batch (the caller is one)
 constexpr size_t kPoolMinBytes = (size_t)4 << 20;  // smaller batches are packed by the caller alone
@@ -224,12 +226,12 @@ void resize_axis(int dn, int sn, std::vector<int>& ofs, std::vector<int16_t>& w0
 }
 
 int build_plan(OrbExtractor* h, int rows, int cols, Plan& P, std::vector<XTab>& xtab, std::vector<YTab>& ytab,
-               std::vector<FastItem>& fitems, std::vector<BlurItem>& bitems) {
+               std::vector<FastItem>& fitems, std::vector<FastItem>& fitems_few, std::vector<BlurItem>& bitems) {
   memset(&P, 0, sizeof(P));
   P.nlevels = h->nlevels; P.rows = rows; P.cols = cols;
   size_t off = 0;
   int cand_off = 0, sel_off = 0;
-  xtab.clear(); ytab.clear(); fitems.clear(); bitems.clear();
+  xtab.clear(); ytab.clear(); fitems.clear(); fitems_few.clear(); bitems.clear();
   for (int l = 0; l < h->nlevels; l++) {
     LevelGeom& L = P.lv[l];
     const float scale = h->inv_sf[l];
@@ -311,6 +313,16 @@ int build_plan(OrbExtractor* h, int rows, int cols, Plan& P, std::vector<XTab>& 
         it.ncells = (int16_t)std::min(G, L.nValidCols - j0);
         fitems.push_back(it);
       }
+    // the same cells for launches of up to kFewFrames frames: one more run per cell row, of even
+    // length (a frame alone has fewer workgroups than the GPU has CUs, and the longest sets the time)
+    const int runs = (L.nValidCols + G - 1) / G + 1;
+    const int Gf = std::max(1, (L.nValidCols + runs - 1) / runs);
+    for (int i = 0; i < L.nValidRows; i++)
+      for (int j0 = 0; j0 < L.nValidCols; j0 += Gf) {
+        FastItem it; it.level = (int16_t)l; it.row = (int16_t)i; it.j0 = (int16_t)j0;
+        it.ncells = (int16_t)std::min(Gf, L.nValidCols - j0);
+        fitems_few.push_back(it);
+      }
     for (int ty = 0; ty * blur_tile_h() < L.h; ty++)
       for (int tx = 0; tx * blur_tile_w() < L.w; tx++) {
         BlurItem it; it.level = (int16_t)l; it.tx = (int16_t)tx; it.ty = (int16_t)ty; it.pad = 0;
@@ -325,14 +337,15 @@ int build_plan(OrbExtractor* h, int rows, int cols, Plan& P, std::vector<XTab>& 
 
 int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   if (h->have_plan && h->plan.rows == rows && h->plan.cols == cols && nframes <= h->cap_frames) return ORBHIP_OK;
-  Plan P; std::vector<XTab> xtab; std::vector<YTab> ytab; std::vector<FastItem> fi; std::vector<BlurItem> bi;
-  int rc = build_plan(h, rows, cols, P, xtab, ytab, fi, bi);
+  Plan P; std::vector<XTab> xtab; std::vector<YTab> ytab; std::vector<FastItem> fi, fi_few; std::vector<BlurItem> bi;
+  int rc = build_plan(h, rows, cols, P, xtab, ytab, fi, fi_few, bi);
   if (rc != ORBHIP_OK) return rc;
   // FAST items of levels whose cell views are short enough for one more workgroup per CU go first:
   // they are launched with the smaller LDS footprint, the others after them
   const int dense_rows = fast_rows_dense();
   const size_t n_short = std::stable_partition(fi.begin(), fi.end(), [&](const FastItem& it) {
                            return P.lv[it.level].hCell + 6 <= dense_rows; }) - fi.begin();
+  fi.insert(fi.end(), fi_few.begin(), fi_few.end());  // one device array: the items for batches, then those for a few frames
   ORB_HIP_CHECK(hipDeviceSynchronize());
   const int cap = std::max(nframes, (h->have_plan && h->plan.rows == rows && h->plan.cols == cols) ? h->cap_frames : 0);
   free_plan_buffers(h);
@@ -421,6 +434,7 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   ORB_HIP_CHECK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
   h->plan = P; h->fast_items = fi; h->blur_items = bi;
   h->fast_items_short = (int)n_short;
+  h->fast_items_few = (int)fi_few.size();
   h->ot_slots = 0;
   for (int l = 0; l < P.nlevels; l++)
     h->ot_slots = std::max(h->ot_slots, std::max(P.lv[l].quota + 3, 4 * P.lv[l].nIni) + P.lv[l].nIni + 8);
@@ -458,8 +472,15 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
       launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[1], st));
-  launch_fast(h->d_pyr, P, h->d_fast_items, (int)h->fast_items.size(), nframes <= kSmallBatchFrames ? 0 : h->fast_items_short, h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
-              nframes, st);
+  {
+    const int n_all = (int)h->fast_items.size(), n_batch = n_all - h->fast_items_few;
+    if (nframes <= kFewFrames)
+      launch_fast(h->d_pyr, P, h->d_fast_items + n_batch, h->fast_items_few, 0, h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
+                  nframes, st);
+    else
+      launch_fast(h->d_pyr, P, h->d_fast_items, n_batch, nframes <= kSmallBatchFrames ? 0 : h->fast_items_short, h->d_cand,
+                  h->d_cand_cnt, h->iniTh, h->minTh, nframes, st);
+  }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));
   ORB_HIP_CHECK(launch_octree(h->d_cand, h->d_cand_cnt, h->d_pnode, h->d_sel, h->d_sel_cnt, P, h->ot_slots, nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[3], st));
@@ -601,8 +622,8 @@ int orb_extractor_get_level_quotas(const OrbExtractor* h, int* quotas, int* umax
 
 int orb_extractor_max_keypoints(OrbExtractor* h, int rows, int cols) {
   if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
-  Plan P; std::vector<XTab> xt; std::vector<YTab> yt; std::vector<FastItem> fi; std::vector<BlurItem> bi;
-  int rc = build_plan(h, rows, cols, P, xt, yt, fi, bi);
+  Plan P; std::vector<XTab> xt; std::vector<YTab> yt; std::vector<FastItem> fi, fi_few; std::vector<BlurItem> bi;
+  int rc = build_plan(h, rows, cols, P, xt, yt, fi, fi_few, bi);
   if (rc != ORBHIP_OK) return rc;
   return P.sel_total;
 }
