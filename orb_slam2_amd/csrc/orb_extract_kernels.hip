@@ -955,7 +955,8 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
       } else {
         const unsigned long long k = S.skey[i];
         r = 0;
-        for (int j = 0; j < E; j++) r += S.skey[j] > k;
+#pragma unroll 8
+        for (int j = 0; j < E; j++) r += S.skey[j] > k;  // (unrolled: the loads of 8 keys are in flight together)
         s = S.elist[i];
         S.order[r] = (short)s;
       }
@@ -1070,6 +1071,7 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
   for (int i = tid; i < M; i += OT_THREADS) {
     const int k = kd[i];
     int r = 0;
+#pragma unroll 4
     for (int j = 0; j < M; j += 4) {
       const int4 q = *reinterpret_cast<const int4*>(&kd[j]);
       r += (q.x > k) + (q.y > k) + (q.z > k) + (q.w > k);
