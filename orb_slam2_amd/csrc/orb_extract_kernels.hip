@@ -1065,18 +1065,51 @@ __device__ __forceinline__ void octree_body(OtShared<OT_MAXS>& S, const uint32_t
     if (S.count[s] > 0) S.elist[atomicAdd(&S.vars[V_NE], 1)] = (short)s;
   __syncthreads();
   const int M = S.vars[V_NE];
-  int* kd = S.ccount;
-  for (int i = tid; i < ((M + 3) & ~3); i += OT_THREADS) kd[i] = i < M ? S.key[S.elist[i]] : -1;
-  __syncthreads();
-  for (int i = tid; i < M; i += OT_THREADS) {
-    const int k = kd[i];
-    int r = 0;
-#pragma unroll 4
-    for (int j = 0; j < M; j += 4) {
-      const int4 q = *reinterpret_cast<const int4*>(&kd[j]);
-      r += (q.x > k) + (q.y > k) + (q.z > k) + (q.w > k);
+  // Keys are distinct creation numbers below V_NEXTSEQ, so the rank of a node is the number of
+  // surviving keys above its own: a bitmap of the surviving keys, the population counts of its
+  // words summed from the top, and one word's bits above the key.  (The node count bounds the
+  // keys only loosely: a node whose points all fall into one quadrant gets a new key every
+  // pass; where the bitmap would not fit, every node counts the greater keys instead.)
+  const int nkeys = S.vars[V_NEXTSEQ];
+  const int nwords = (nkeys + 63) >> 6;
+  unsigned long long* bm = reinterpret_cast<unsigned long long*>(S.ccount);  // nwords words, then nwords ints
+  int* above = S.ccount + 2 * nwords;
+  const bool use_bitmap = 3 * nwords <= OT_MAXS * 4;
+  if (use_bitmap) {
+    for (int w = tid; w < nwords; w += OT_THREADS) bm[w] = 0;
+    __syncthreads();
+    for (int i = tid; i < M; i += OT_THREADS) {
+      const int k = S.key[S.elist[i]];
+      atomicOr(&bm[k >> 6], 1ull << (k & 63));
     }
-    const unsigned long long b = S.skey[S.elist[i]];
+    __syncthreads();
+    for (int w = tid; w < nwords; w += OT_THREADS) {
+      int c = 0;
+      for (int v = w + 1; v < nwords; v++) c += __popcll(bm[v]);
+      above[w] = c;
+    }
+    __syncthreads();
+  } else {
+    int* kd = S.ccount;
+    for (int i = tid; i < ((M + 3) & ~3); i += OT_THREADS) kd[i] = i < M ? S.key[S.elist[i]] : -1;
+    __syncthreads();
+  }
+  for (int i = tid; i < M; i += OT_THREADS) {
+    const int s = S.elist[i];
+    int r = 0;
+    if (use_bitmap) {
+      const int k = S.key[s];
+      r = above[k >> 6] + __popcll((bm[k >> 6] >> (k & 63)) >> 1);
+    } else {
+      const int* kd = S.ccount;
+      const int k = kd[i];
+#pragma unroll 4
+      for (int j = 0; j < M; j += 4) {
+        const int4 q = *reinterpret_cast<const int4*>(&kd[j]);
+        r += (q.x > k) + (q.y > k) + (q.z > k) + (q.w > k);
+      }
+    }
+    const unsigned long long b = S.skey[s];
     const unsigned long long canon = ((1ull << 40) - 1) - (b & ((1ull << 40) - 1));
     const uint32_t x = (uint32_t)(canon & 0xFFF), y = (uint32_t)((canon >> 12) & 0xFFF);
     if (r < L.sel_cap) sel[r] = x | (y << kCoordBits) | ((uint32_t)(b >> 40) << 24);
