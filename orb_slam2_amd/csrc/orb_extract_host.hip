@@ -15,8 +15,8 @@
 namespace orbhip {
 
 // launchers and limits defined next to the kernels
-void launch_pyr_level0(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, int, hipStream_t);
-void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, const int*, uint8_t*, const Plan&, int, hipStream_t);
+void launch_pyr_level0(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, int*, int, hipStream_t);
+void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, const int*, uint8_t*, const Plan&, int*, int, hipStream_t);
 void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
 void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, int, uint32_t*, int*, int, int, int, hipStream_t);
 int fast_rows_dense();
@@ -456,10 +456,10 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
     }
     ev = h->ev.data() + (size_t)h->prof_calls * (ORBHIP_NUM_STAGES + 1);
   }
-  ORB_HIP_CHECK(hipMemsetAsync(h->d_cand_cnt, 0, sizeof(int) * (size_t)P.nlevels * nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[0], st));
-  if (h->channels == 1) launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, nframes, st);
-  else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->gray, h->d_pyr, P, nframes, st);
+  // (the level-0 kernel also clears the frames' candidate counters)
+  if (h->channels == 1) launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, h->d_cand_cnt, nframes, st);
+  else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->gray, h->d_pyr, P, h->d_cand_cnt, nframes, st);
   for (int l = 1; l < P.nlevels; l++) {
     const OrbExtractor::TileInfo& ti = h->tile[l];
     if (ti.ok) {
@@ -591,7 +591,7 @@ void orb_extractor_destroy(OrbExtractor* h) {
   DeviceGuard g(h->device);
   hipDeviceSynchronize();
   free_plan_buffers(h);
-  hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_nout);
+  hipFree(h->d_img); hipFree(h->d_desc);  // (keypoints and counts live in the descriptors' allocation)
   if (h->h_img) hipHostFree(h->h_img);
   if (h->h_out) hipHostFree(h->h_out);
   delete h->pool;
@@ -721,13 +721,17 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   const size_t need = (size_t)n_frames * max_kp;
   if (need > h->out_cap || n_frames > h->out_frames) {
     ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
-    hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_nout);
-    h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr; h->out_cap = 0; h->out_frames = 0;
-    ORB_HIP_CHECK(hipMalloc(&h->d_kps, sizeof(OrbKeyPoint) * need));
-    ORB_HIP_CHECK(hipMalloc(&h->d_desc, 32 * need));
-    ORB_HIP_CHECK(hipMalloc(&h->d_nout, sizeof(int) * n_frames));
-    h->out_cap = need; h->out_frames = n_frames;
+    // one allocation, laid out like the pinned staging (descriptors, keypoints, counts), so that the
+    // results come back in one copy
+    const size_t cap = std::max(need, h->out_cap), capf = (size_t)std::max(n_frames, h->out_frames);
+    hipFree(h->d_desc);
+    h->d_desc = nullptr; h->out_cap = 0; h->out_frames = 0;
+    ORB_HIP_CHECK(hipMalloc(&h->d_desc, cap * (32 + sizeof(OrbKeyPoint)) + sizeof(int) * capf));
+    h->out_cap = cap; h->out_frames = (int)capf;
   }
+  // (the layout follows this call's sizes, whatever the allocation's capacity)
+  h->d_kps = reinterpret_cast<OrbKeyPoint*>(h->d_desc + need * 32);
+  h->d_nout = reinterpret_cast<int*>(h->d_desc + need * (32 + sizeof(OrbKeyPoint)));
   hipStream_t st = h->stream;
   // Host images go through a pinned staging buffer, packed to rows of `row_bytes` bytes: one
   // DMA for the batch (a strided copy from pageable memory is far slower than the kernels).
@@ -763,7 +767,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
                                    (size_t)kn * frame_bytes, hipMemcpyHostToDevice, st));
     }
   }
-  // results come back through pinned staging as well: three DMAs for the batch, then the valid
+  // results come back through pinned staging as well: one DMA for the batch, then the valid
   // part of every frame is copied to the caller's arrays
   const size_t out_bytes = need * (sizeof(OrbKeyPoint) + 32) + sizeof(int) * (size_t)n_frames;
   if (out_bytes > h->h_out_bytes) {
@@ -773,16 +777,14 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
     ORB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_out), out_bytes, hipHostMallocDefault));
     h->h_out_bytes = out_bytes;
   }
-  OrbKeyPoint* s_kps = reinterpret_cast<OrbKeyPoint*>(h->h_out);
-  uint8_t* s_desc = h->h_out + need * sizeof(OrbKeyPoint);
-  int* s_n = reinterpret_cast<int*>(s_desc + need * 32);
+  uint8_t* s_desc = h->h_out;
+  OrbKeyPoint* s_kps = reinterpret_cast<OrbKeyPoint*>(h->h_out + need * 32);
+  int* s_n = reinterpret_cast<int*>(h->h_out + need * (32 + sizeof(OrbKeyPoint)));
   auto device_work = [&](bool with_upload) -> int {
     if (with_upload) ORB_HIP_CHECK(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, st));
     int r = enqueue(h, n_frames, h->d_img, row_bytes, (size_t)rows * row_bytes, max_kp, h->d_kps, h->d_desc, h->d_nout, st);
     if (r != ORBHIP_OK) return r;
-    ORB_HIP_CHECK(hipMemcpyAsync(s_n, h->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, st));
-    ORB_HIP_CHECK(hipMemcpyAsync(s_kps, h->d_kps, sizeof(OrbKeyPoint) * need, hipMemcpyDeviceToHost, st));
-    ORB_HIP_CHECK(hipMemcpyAsync(s_desc, h->d_desc, 32 * need, hipMemcpyDeviceToHost, st));
+    ORB_HIP_CHECK(hipMemcpyAsync(h->h_out, h->d_desc, out_bytes, hipMemcpyDeviceToHost, st));
     return ORBHIP_OK;
   };
   if (small && !h->profiling) {

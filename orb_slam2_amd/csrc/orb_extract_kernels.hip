@@ -37,7 +37,10 @@ struct L0Map {
 };
 __global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restrict__ img, size_t stride,
                                                          size_t frame_stride, uint8_t* __restrict__ pyr,
-                                                         unsigned long long slab, LevelGeom L, L0Map M) {
+                                                         unsigned long long slab, LevelGeom L, L0Map M,
+                                                         int* __restrict__ cand_cnt, int nlevels) {
+  // the frame's candidate counters start at zero (FAST, later in the stream, adds to them)
+  if (blockIdx.y == 0 && threadIdx.x < nlevels) cand_cnt[blockIdx.x * nlevels + threadIdx.x] = 0;
   // a thread moves L0_PIECES pieces a fixed distance apart; all their loads are issued before
   // the first result is needed, so that more bytes are in flight per wavefront
   const int half = (M.total + L0_PIECES - 1) / L0_PIECES;
@@ -123,7 +126,9 @@ template <int CH>
 __global__ __launch_bounds__(256) void pyr_level0_color_kernel(const uint8_t* __restrict__ img, size_t stride,
                                                                size_t frame_stride, uint8_t* __restrict__ pyr,
                                                                unsigned long long slab, LevelGeom L, int k0, int k1,
-                                                               int k2, int rnd, int shift) {
+                                                               int k2, int rnd, int shift, int* __restrict__ cand_cnt,
+                                                               int nlevels) {
+  if (blockIdx.y == 0 && threadIdx.x < nlevels) cand_cnt[blockIdx.x * nlevels + threadIdx.x] = 0;
   const int nchunk = L.pitch >> 4;
   const int t = blockIdx.y * 256 + threadIdx.x;
   const int row = t / nchunk;  // padded row
@@ -1507,7 +1512,7 @@ hipError_t upload_orient_tables() {
 
 // ---- launchers --------------------------------------------------------------
 void launch_pyr_level0(const uint8_t* img, size_t stride, size_t frame_stride, uint8_t* pyr, const Plan& P,
-                       int nframes, hipStream_t st) {
+                       int* cand_cnt, int nframes, hipStream_t st) {
   const LevelGeom& L = P.lv[0];
   const int nchunk = L.pitch / 16, nrows = L.h + 2 * kEdge;
   // interior pieces: 16 c - kXOff >= 4 and 16 c - kXOff + 20 <= w
@@ -1522,11 +1527,12 @@ void launch_pyr_level0(const uint8_t* img, size_t stride, size_t frame_stride, u
   M.total = nchunk * nrows;
   const int per_thread = (M.total + L0_PIECES - 1) / L0_PIECES;
   dim3 grid(nframes, (per_thread + 255) / 256);
-  hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, M);
+  hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, M, cand_cnt,
+                     P.nlevels);
 }
 void launch_pyr_level0_color(const uint8_t* img, size_t stride, size_t frame_stride, int channels, bool rgb_order,
-                             const int* gray /* weight R, G, B, shift */, uint8_t* pyr, const Plan& P, int nframes,
-                             hipStream_t st) {
+                             const int* gray /* weight R, G, B, shift */, uint8_t* pyr, const Plan& P, int* cand_cnt,
+                             int nframes, hipStream_t st) {
   const LevelGeom& L = P.lv[0];
   const int pieces = (L.pitch / 16) * (L.h + 2 * kEdge);
   dim3 grid(nframes, (pieces + 255) / 256);
@@ -1534,10 +1540,10 @@ void launch_pyr_level0_color(const uint8_t* img, size_t stride, size_t frame_str
   const int k0 = rgb_order ? kr : kb, k2 = rgb_order ? kb : kr;
   if (channels == 3)
     hipLaunchKernelGGL(pyr_level0_color_kernel<3>, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, k0,
-                       kg, k2, rnd, shift);
+                       kg, k2, rnd, shift, cand_cnt, P.nlevels);
   else
     hipLaunchKernelGGL(pyr_level0_color_kernel<4>, grid, dim3(256), 0, st, img, stride, frame_stride, pyr, P.slab, L, k0,
-                       kg, k2, rnd, shift);
+                       kg, k2, rnd, shift, cand_cnt, P.nlevels);
 }
 void launch_pyr_resize(uint8_t* pyr, const Plan& P, int level, const XTab* xt, const YTab* yt, int nframes,
                        hipStream_t st) {
