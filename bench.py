@@ -328,11 +328,12 @@ def main():
     if rank == 0:
         # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh + tools/pmc_to_traffic.py),
         # valid for the batch size they were taken at
-        traffic = {}
+        traffic, launches = {}, {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
             if tj["frames_per_launch"] == B:
-                traffic = {k.replace("_kernel", ""): v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
+                traffic = {k.replace("_kernel", ""): v.get("hbm_bytes_per_step", v["hbm_bytes_per_launch"]) for k, v in tj["kernels"].items()}
+                launches = {k.replace("_kernel", ""): v.get("launches_per_step", 1) for k, v in tj["kernels"].items()}
         except (OSError, ValueError, KeyError):
             pass
         ab = algorithmic_bytes(ROWS, COLS)
@@ -352,7 +353,10 @@ def main():
                        "keypoints_per_frame": round(nkp / B, 1), "matches_per_pair": round(nmatch / npairs, 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(gbs[dom], 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(gbs[dom] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom),
-                         "algorithmic_bytes_per_launch": ab[dom] * B, "algorithmic_bytes_per_frame": ab[dom]},
+                         "algorithmic_bytes_per_launch": ab[dom] * B, "algorithmic_bytes_per_frame": ab[dom],
+                         # kernels that take several launches per step (FAST: one per view height class) are
+                         # priced as one: bytes and time of all of them, back to back on the stream
+                         "launches_per_step": launches.get(dom, 1)},
             "stages_ms_per_step": stages,
             "stage_gbs": {k: round(v, 1) for k, v in gbs.items()},
             "cpu_baseline": cpu,

@@ -13,25 +13,33 @@ import sys
 from collections import defaultdict
 
 
-def mean_per_kernel(d, counter):
+def per_kernel(d, counter):
+    """kernel -> (mean per launch, launches)"""
     acc = defaultdict(list)
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(fn)):
             if row["Counter_Name"] == counter:
                 acc[row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
 def main():
     fetch_dir, write_dir, out, frames = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-    f, w = mean_per_kernel(fetch_dir, "FETCH_SIZE"), mean_per_kernel(write_dir, "WRITE_SIZE")
+    fc, wc = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    # steps of the profiled run = launches of a kernel that runs once per step (the quad-tree); a kernel
+    # with several launches per step (the resize: one per level; FAST: two view heights) gets their sum too
+    steps = max([n for k, (_, n) in fc.items() if "octree_kernel" in k] or [1])
     table = {}
-    for k in sorted(f):
+    for k in sorted(fc):
         if not k.startswith("orbhip"):
             continue
-        rd, wr = 2.0 * f[k] * 1024.0, w.get(k, 0.0) * 1024.0
-        table[k.replace("orbhip::", "")] = {"fetch_size_kib_raw": round(f[k], 1), "write_size_kib": round(w.get(k, 0.0), 1),
-                                            "read_bytes": round(rd), "write_bytes": round(wr), "hbm_bytes_per_launch": round(rd + wr)}
+        f, n = fc[k]
+        w = wc.get(k, (0.0, 0))[0]
+        rd, wr = 2.0 * f * 1024.0, w * 1024.0
+        per_step = n / steps
+        table[k.replace("orbhip::", "")] = {"fetch_size_kib_raw": round(f, 1), "write_size_kib": round(w, 1),
+                                            "read_bytes": round(rd), "write_bytes": round(wr), "hbm_bytes_per_launch": round(rd + wr),
+                                            "launches_per_step": round(per_step, 3), "hbm_bytes_per_step": round((rd + wr) * per_step)}
     json.dump({"frames_per_launch": frames, "correction": "read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB",
                "kernels": table}, open(out, "w"), indent=1)
     print(json.dumps(table, indent=1))
