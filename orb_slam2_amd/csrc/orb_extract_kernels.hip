@@ -390,7 +390,7 @@ __device__ __forceinline__ bool fast_nms_keep(const uint8_t* q, int v, bool hasL
 }
 
 // floor(off / F_PITCH), and floor(n / d) for n, d < 256 with m = 65536 / d + 1 by multiplication
-// (checked exhaustively on the host side of the tests).
+// (the identity is checked over its whole range in tests/test_arith_cpu.py).
 static_assert(F_PITCH == 256, "div_pitch shifts by 8");
 __device__ __forceinline__ int div_pitch(int off) { return off >> 8; }
 __device__ __forceinline__ int div_small(int n, int m) { return (n * m) >> 16; }
