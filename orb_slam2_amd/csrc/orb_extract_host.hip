@@ -20,6 +20,8 @@ void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, const in
 void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
 void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, int, uint32_t*, int*, int, int, int, hipStream_t);
 int fast_rows_dense();
+void launch_pyr_resize_dual(uint8_t*, const Plan&, int, const uint32_t*, const uint32_t*, const YTab*, const int2*, int,
+                            const int2*, int, const int2*, int, int, int, int, int, int, int, int, hipStream_t);
 hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, int, hipStream_t);
 void launch_blur(const uint8_t*, uint8_t*, const Plan&, const BlurItem*, int, const int*, int, hipStream_t);
 hipError_t upload_orient_tables();
@@ -143,6 +145,9 @@ struct OrbExtractor {
   // frame is spread over many workgroups instead of waiting for a handful of long ones
   struct TileInfo { bool ok = false; int xtp_off = 0, xr_off = 0, ngx = 0, src_pitch = 0; int yr_off[2] = {0, 0}, ngy[2] = {0, 0}, src_rows[2] = {0, 0}; };
   TileInfo tile[kMaxLevels];
+  // launches of a few frames: level l and level l + 1 in one launch (pair[l].ok), see pyr_resize_dual_kernel
+  struct PairInfo { bool ok = false; int spitch0 = 0, pitchB = 0, offB = 0, lds = 0; };
+  PairInfo pair[kMaxLevels];
   uint32_t* d_xtp = nullptr;
   int2* d_ranges = nullptr;
   std::vector<FastItem> fast_items;
@@ -420,6 +425,28 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
       }
       h->tile[l] = ti;
     }
+    // pairs of levels for launches of a few frames (small tiles): what a tile of level l + 1 needs of
+    // level l, and that of level l - 1
+    for (int l = 1; l < kMaxLevels; l++) h->pair[l] = OrbExtractor::PairInfo();
+    for (int l = 1; l + 1 < P.nlevels; l += 2) {
+      const OrbExtractor::TileInfo &t1 = h->tile[l], &t2 = h->tile[l + 1];
+      OrbExtractor::PairInfo pi;
+      if (!t1.ok || !t2.ok || t2.ngx != 1) continue;
+      const LevelGeom &L0 = P.lv[l - 1], &L1 = P.lv[l];
+      pi.spitch0 = (L0.w + 1 + 15) & ~15;
+      pi.pitchB = (L1.w + 4 + 15) & ~15;
+      int rows0 = 0, rows1 = 0;
+      for (int g = 0; g < t2.ngy[1]; g++) {
+        const int2 y2 = ranges[t2.yr_off[1] + g];
+        const YTab &ta = ytab[L1.ytab_off + y2.x], &tb = ytab[L1.ytab_off + y2.y];
+        rows1 = std::max(rows1, y2.y - y2.x + 1);
+        rows0 = std::max(rows0, (int)std::max(tb.sy0, tb.sy1) - (int)std::min(ta.sy0, ta.sy1) + 1);
+      }
+      pi.offB = rows0 * pi.spitch0;
+      pi.lds = std::max(pi.offB + rows1 * pi.pitchB, t1.src_rows[1] * t1.src_pitch);
+      pi.ok = rows1 <= 64 && pi.lds <= 60 * 1024;
+      h->pair[l] = pi;
+    }
     ORB_HIP_CHECK(hipMalloc(&h->d_xtp, sizeof(uint32_t) * std::max<size_t>(xtp.size(), 4)));
     ORB_HIP_CHECK(hipMalloc(&h->d_ranges, sizeof(int2) * std::max<size_t>(ranges.size(), 1)));
     ORB_HIP_CHECK(hipMemcpy(h->d_xtp, xtp.data(), sizeof(uint32_t) * xtp.size(), hipMemcpyHostToDevice));
@@ -462,6 +489,16 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->gray, h->d_pyr, P, h->d_cand_cnt, nframes, st);
   for (int l = 1; l < P.nlevels; l++) {
     const OrbExtractor::TileInfo& ti = h->tile[l];
+    if (nframes <= kSmallBatchFrames && h->pair[l].ok) {
+      const OrbExtractor::TileInfo& t2 = h->tile[l + 1];
+      const OrbExtractor::PairInfo& pi = h->pair[l];
+      launch_pyr_resize_dual(h->d_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_xtp + t2.xtp_off, h->d_ytab,
+                             h->d_ranges + ti.xr_off, ti.ngx, h->d_ranges + ti.yr_off[1], ti.ngy[1],
+                             h->d_ranges + t2.yr_off[1], t2.ngy[1], pyr_tile_rows_small(), ti.src_pitch, pi.spitch0,
+                             pi.pitchB, pi.offB, pi.lds, nframes, st);
+      l++;  // level l + 1 is done as well
+      continue;
+    }
     if (ti.ok) {
       const int v = nframes <= kSmallBatchFrames ? 1 : 0;
       launch_pyr_resize_tile(h->d_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off, ti.ngx,

@@ -217,16 +217,12 @@ constexpr int PR_TC = 1024, PR_TR = 8, PR_TR_SMALL = 4, PR_THREADS = 256;  // ti
 constexpr int PR_SROWS = 32, PR_MAXPITCH = 1536;  // limits of the staged source region
 static_assert(sizeof(YTab) == 8, "a row's vertical taps are fetched as one 64-bit word");
 
-__global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __restrict__ pyr,
-                                                                     unsigned long long slab, LevelGeom Ls,
-                                                                     LevelGeom Ld, const uint32_t* __restrict__ xtp,
-                                                                     const YTab* __restrict__ yt,
-                                                                     const int2* __restrict__ xrange,
-                                                                     const int2* __restrict__ yrange, int PR_SPITCH,
-                                                                     int tile_rows) {
-  // staged source rows: the launch sizes this to the level's widest / tallest tile
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
-  const int gx = blockIdx.z, gy = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void pr_tile(uint8_t* __restrict__ pyr, unsigned long long slab, const LevelGeom& Ls,
+                                        const LevelGeom& Ld, const uint32_t* __restrict__ xtp,
+                                        const YTab* __restrict__ yt, const int2* __restrict__ xrange,
+                                        const int2* __restrict__ yrange, int PR_SPITCH, int tile_rows, int gx, int gy,
+                                        int f, uint8_t* s_src) {
+  const int tid = threadIdx.x;
   const int2 X = xrange[gx], Y = yrange[gy];
   const int a0 = (X.x + kXOff) & ~15;                  // first staged slab column
   const int n16 = (X.y + kXOff - a0 + 16) >> 4;        // 16-byte pieces per row
@@ -301,6 +297,123 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
     prev_row = s1;
     *reinterpret_cast<uint32_t*>(dst + (size_t)r * Ld.pitch) = out;
   }
+}
+
+
+__global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __restrict__ pyr,
+                                                                     unsigned long long slab, LevelGeom Ls,
+                                                                     LevelGeom Ld, const uint32_t* __restrict__ xtp,
+                                                                     const YTab* __restrict__ yt,
+                                                                     const int2* __restrict__ xrange,
+                                                                     const int2* __restrict__ yrange, int PR_SPITCH,
+                                                                     int tile_rows) {
+  // staged source rows: the launch sizes this to the level's widest / tallest tile
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
+  pr_tile(pyr, slab, Ls, Ld, xtp, yt, xrange, yrange, PR_SPITCH, tile_rows, blockIdx.z, blockIdx.y, blockIdx.x, s_src);
+}
+
+// Two levels in one launch, for launches of a few frames, where every level is a launch of a
+// few microseconds that has to wait for the one before: workgroups with blockIdx.y < ngy1 are
+// tiles of level l (as above); the others are tiles of level l + 1, computed from level l - 1 as
+// well: the rows of level l that a tile needs are made in LDS first (all interior columns; the
+// same arithmetic, so the same bytes as the level-l tiles write), then the tile from them.
+// Level l + 1 must fit one column tile.
+__global__ __launch_bounds__(PR_THREADS) void pyr_resize_dual_kernel(
+    uint8_t* __restrict__ pyr, unsigned long long slab, LevelGeom L0, LevelGeom L1, LevelGeom L2,
+    const uint32_t* __restrict__ xtp1, const uint32_t* __restrict__ xtp2, const YTab* __restrict__ yt,
+    const int2* __restrict__ xrange1, const int2* __restrict__ yrange1, const int2* __restrict__ yrange2, int spitch1,
+    int tile_rows, int ngy1, int spitch0, int pitchB, int offB) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dual[];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if ((int)blockIdx.y < ngy1) {  // uniform
+    pr_tile(pyr, slab, L0, L1, xtp1, yt + L1.ytab_off, xrange1, yrange1, spitch1, tile_rows, blockIdx.z, blockIdx.y, f, s_dual);
+    return;
+  }
+  if (blockIdx.z != 0) return;
+  const int gy = blockIdx.y - ngy1;
+  const int2 Y2 = yrange2[gy];  // rows of level l this tile of level l + 1 reads
+  const YTab* yt1 = yt + L1.ytab_off;
+  const int nrows1 = Y2.y - Y2.x + 1;
+  // their vertical taps, one row per lane
+  unsigned long long y1l = 0;
+  if (lane < nrows1) y1l = *reinterpret_cast<const unsigned long long*>(&yt1[Y2.x + lane]);
+  const int tmin = (int)((uint32_t)__builtin_amdgcn_readlane((uint32_t)y1l, 0) & 0xFFFFu);
+  const int tmax = (int)((uint32_t)__builtin_amdgcn_readlane((uint32_t)y1l, nrows1 - 1) >> 16);
+  // stage rows tmin .. tmax of level l - 1, interior columns (and the one after them)
+  uint8_t* const s_src = s_dual;
+  uint8_t* const s_b = s_dual + offB;
+  {
+    const int n16 = (L0.w + 1 + 15) >> 4, nrows0 = tmax - tmin + 1;
+    const uint8_t* src = pyr + (size_t)f * slab + L0.off + (size_t)(tmin + kEdge) * L0.pitch + kXOff;
+    for (int r = tid >> 6; r < nrows0; r += PR_THREADS / 64)
+      for (int c = lane; c < n16; c += 64)
+        *reinterpret_cast<uint4*>(&s_src[r * spitch0 + 16 * c]) =
+            *reinterpret_cast<const uint4*>(src + (size_t)r * L0.pitch + 16 * c);
+  }
+  __syncthreads();
+  auto mulhi24 = [](uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)) >> 32); };
+  // one pass of the resize: rows [ra, rb) (the taps of row ra + i in lane i of ytl), source rows in S
+  // (row sbase at offset 0), four columns whose table entries are e; returns through `emit(row, dword)`
+  auto pass = [&](const uint8_t* S, int sp, int sbase, const uint4 e, unsigned long long ytl, int nrows, auto emit) {
+    const uint32_t ev[4] = {e.x, e.y, e.z, e.w};
+    int col[4], w0[4], w1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int a1 = (int)(ev[k] >> 16);
+      const bool valid = a1 != 0xFFFF;
+      col[k] = valid ? (int)(ev[k] & 0xFFFF) : 0;
+      w1[k] = valid ? a1 : 0;
+      w0[k] = valid ? 2048 - a1 : 0;
+    }
+    uint32_t hprev[4] = {0, 0, 0, 0};
+    int prev_row = -1;
+    for (int i = 0; i < nrows; i++) {
+      const uint32_t ylo = __builtin_amdgcn_readlane((uint32_t)ytl, i);
+      const uint32_t yhi = __builtin_amdgcn_readlane((uint32_t)(ytl >> 32), i);
+      const int s0 = (int)(ylo & 0xFFFFu), s1 = (int)(ylo >> 16);
+      uint32_t h0[4], h1[4];
+      if (s0 == prev_row) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) h0[k] = hprev[k];
+      } else {
+        const uint8_t* R = S + (s0 - sbase) * sp;
+#pragma unroll
+        for (int k = 0; k < 4; k++) h0[k] = (uint32_t)(R[col[k]] * w0[k] + R[col[k] + 1] * w1[k]) & 0xFFFFF0u;
+      }
+      if (s1 == s0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) h1[k] = h0[k];
+      } else {
+        const uint8_t* R = S + (s1 - sbase) * sp;
+#pragma unroll
+        for (int k = 0; k < 4; k++) h1[k] = (uint32_t)(R[col[k]] * w0[k] + R[col[k] + 1] * w1[k]) & 0xFFFFF0u;
+      }
+      const uint32_t b0 = (uint32_t)(yhi & 0xFFFFu) << 12, b1 = (uint32_t)(yhi >> 16) << 12;
+      uint32_t out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        out |= ((mulhi24(b0, h0[k]) + mulhi24(b1, h1[k]) + 2u) >> 2) << (8 * k);
+        hprev[k] = h1[k];
+      }
+      prev_row = s1;
+      emit(i, out);
+    }
+  };
+  // level l: rows Y2.x .. Y2.y, interior columns, into s_b
+  for (int cg = tid; 4 * cg < L1.w; cg += PR_THREADS)
+    pass(s_src, spitch0, tmin, *reinterpret_cast<const uint4*>(&xtp1[kXOff + 4 * cg]), y1l, nrows1,
+         [&](int i, uint32_t v) { *reinterpret_cast<uint32_t*>(&s_b[i * pitchB + 4 * cg]) = v; });
+  __syncthreads();
+  // level l + 1: the tile's rows from them
+  const int c = 4 * tid;
+  if (c >= L2.pitch) return;
+  const int rbeg = gy * tile_rows, rend = min(rbeg + tile_rows, L2.h + 2 * kEdge);
+  unsigned long long y2l = 0;
+  if (lane < rend - rbeg)
+    y2l = *reinterpret_cast<const unsigned long long*>(&yt[L2.ytab_off + refl101(rbeg + lane - kEdge, L2.h)]);
+  uint8_t* dst = pyr + (size_t)f * slab + L2.off + c;
+  pass(s_b, pitchB, Y2.x, *reinterpret_cast<const uint4*>(&xtp2[c]), y2l, rend - rbeg,
+       [&](int i, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + (size_t)(rbeg + i) * L2.pitch) = v; });
 }
 
 // ---------------------------------------------------------------------------
@@ -1558,6 +1671,14 @@ void launch_pyr_resize_tile(uint8_t* pyr, const Plan& P, int level, const uint32
   hipLaunchKernelGGL(pyr_resize_tile_kernel, dim3(nframes, ngy, ngx), dim3(PR_THREADS), (size_t)src_rows * src_pitch, st,
                      pyr, P.slab, P.lv[level - 1], P.lv[level], xtp, yt + P.lv[level].ytab_off, xrange, yrange,
                      src_pitch, tile_rows);
+}
+void launch_pyr_resize_dual(uint8_t* pyr, const Plan& P, int level, const uint32_t* xtp1, const uint32_t* xtp2,
+                            const YTab* yt, const int2* xrange1, int ngx1, const int2* yrange1, int ngy1,
+                            const int2* yrange2, int ngy2, int tile_rows, int spitch1, int spitch0, int pitchB, int offB,
+                            int lds_bytes, int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(pyr_resize_dual_kernel, dim3(nframes, ngy1 + ngy2, ngx1), dim3(PR_THREADS), (size_t)lds_bytes, st, pyr,
+                     P.slab, P.lv[level - 1], P.lv[level], P.lv[level + 1], xtp1, xtp2, yt, xrange1, yrange1, yrange2,
+                     spitch1, tile_rows, ngy1, spitch0, pitchB, offB);
 }
 int pyr_tile_cols() { return PR_TC; }
 int pyr_tile_rows() { return PR_TR; }
