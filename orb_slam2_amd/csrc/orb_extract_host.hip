@@ -20,6 +20,7 @@ void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, const in
 void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
 void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, int, uint32_t*, int*, int, int, int, hipStream_t);
 int fast_rows_dense();
+int fast_use_width_narrow();
 void launch_pyr_resize_dual(uint8_t*, const Plan&, int, const uint32_t*, const uint32_t*, const YTab*, const int2*, int,
                             const int2*, int, const int2*, int, int, int, int, int, int, int, int, hipStream_t);
 hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*, const Plan&, int, int, hipStream_t);
@@ -151,7 +152,7 @@ struct OrbExtractor {
   uint32_t* d_xtp = nullptr;
   int2* d_ranges = nullptr;
   std::vector<FastItem> fast_items;
-  int fast_items_short = 0;  // the first so many items have views of at most fast_rows_dense() rows
+  int fast_items_tall = 0;   // the first so many items have views of more than fast_rows_dense() rows
   int fast_items_few = 0;    // items [size - fast_items_few, size) are the same cells cut for launches of a few frames
   std::vector<BlurItem> blur_items;
   // device buffers
@@ -311,7 +312,9 @@ int build_plan(OrbExtractor* h, int rows, int cols, Plan& P, std::vector<XTab>& 
       }
     }
     // FAST work items: runs of cells per cell row
-    const int G = std::max(1, std::min(fast_max_cells(), fast_use_width() / L.wCell));
+    // (levels whose cell views are taller than fast_rows_dense() are staged at the narrow pitch: shorter runs)
+    const int usew = L.hCell + 6 > fast_rows_dense() ? fast_use_width_narrow() : fast_use_width();
+    const int G = std::max(1, std::min(fast_max_cells(), usew / L.wCell));
     for (int i = 0; i < L.nValidRows; i++)
       for (int j0 = 0; j0 < L.nValidCols; j0 += G) {
         FastItem it; it.level = (int16_t)l; it.row = (int16_t)i; it.j0 = (int16_t)j0;
@@ -345,11 +348,11 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   Plan P; std::vector<XTab> xtab; std::vector<YTab> ytab; std::vector<FastItem> fi, fi_few; std::vector<BlurItem> bi;
   int rc = build_plan(h, rows, cols, P, xtab, ytab, fi, fi_few, bi);
   if (rc != ORBHIP_OK) return rc;
-  // FAST items of levels whose cell views are short enough for one more workgroup per CU go first:
-  // they are launched with the smaller LDS footprint, the others after them
+  // FAST items of levels whose cell views are too tall for six workgroups per CU at the wide LDS
+  // pitch go first (they are staged at the narrow pitch, or launched apart)
   const int dense_rows = fast_rows_dense();
-  const size_t n_short = std::stable_partition(fi.begin(), fi.end(), [&](const FastItem& it) {
-                           return P.lv[it.level].hCell + 6 <= dense_rows; }) - fi.begin();
+  const size_t n_tall = std::stable_partition(fi.begin(), fi.end(), [&](const FastItem& it) {
+                          return P.lv[it.level].hCell + 6 > dense_rows; }) - fi.begin();
   fi.insert(fi.end(), fi_few.begin(), fi_few.end());  // one device array: the items for batches, then those for a few frames
   ORB_HIP_CHECK(hipDeviceSynchronize());
   const int cap = std::max(nframes, (h->have_plan && h->plan.rows == rows && h->plan.cols == cols) ? h->cap_frames : 0);
@@ -460,7 +463,7 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   ORB_HIP_CHECK(hipMemsetAsync(h->d_sel_cnt, 0, sizeof(int) * (size_t)P.nlevels * cap, h->stream));
   ORB_HIP_CHECK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
   h->plan = P; h->fast_items = fi; h->blur_items = bi;
-  h->fast_items_short = (int)n_short;
+  h->fast_items_tall = (int)n_tall;
   h->fast_items_few = (int)fi_few.size();
   h->ot_slots = 0;
   for (int l = 0; l < P.nlevels; l++)
@@ -512,10 +515,10 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   {
     const int n_all = (int)h->fast_items.size(), n_batch = n_all - h->fast_items_few;
     if (nframes <= kFewFrames)
-      launch_fast(h->d_pyr, P, h->d_fast_items + n_batch, h->fast_items_few, 0, h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
+      launch_fast(h->d_pyr, P, h->d_fast_items + n_batch, h->fast_items_few, -1, h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
                   nframes, st);
     else
-      launch_fast(h->d_pyr, P, h->d_fast_items, n_batch, nframes <= kSmallBatchFrames ? 0 : h->fast_items_short, h->d_cand,
+      launch_fast(h->d_pyr, P, h->d_fast_items, n_batch, nframes <= kSmallBatchFrames ? -1 : h->fast_items_tall, h->d_cand,
                   h->d_cand_cnt, h->iniTh, h->minTh, nframes, st);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));

@@ -451,19 +451,20 @@ __device__ __forceinline__ fast_s2 pk_max(fast_s2 a, fast_s2 b) { return __built
 // registers hold the ring and each step of the sliding maximum is eight operations; where a
 // window wraps past p[15] the neighbour register is used with its halves exchanged.
 __device__ __forceinline__ fast_s2 swap2(fast_s2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+template <int FP>
 __device__ __forceinline__ int fast_v1(const uint8_t* p /* centre in LDS */, int t, bool dark_only, bool& again) {
   // all seventeen reads relative to the ring's first byte in memory (p[9]), so that every offset
   // is a non-negative constant that fits the LDS instruction's offset field: one address, no adds
-  constexpr int B = 3 * F_PITCH + 1;
+  constexpr int B = 3 * FP + 1;
   typedef __attribute__((address_space(3))) const uint8_t* lds_bytes;
   uint32_t ba = (uint32_t)(uintptr_t)(lds_bytes)p - B;
   asm("" : "+v"(ba));  // opaque: otherwise the subtraction is folded back into seven negative offsets, an add each
   const lds_bytes b = (lds_bytes)(uintptr_t)ba;
   const int c = b[B];
-  const int offs[16] = {B + 3 * F_PITCH,     B + 3 * F_PITCH + 1, B + 2 * F_PITCH + 2, B + F_PITCH + 3,
-                        B + 3,               B - F_PITCH + 3,     B - 2 * F_PITCH + 2, B - 3 * F_PITCH + 1,
-                        B - 3 * F_PITCH,     B - 3 * F_PITCH - 1, B - 2 * F_PITCH - 2, B - F_PITCH - 3,
-                        B - 3,               B + F_PITCH - 3,     B + 2 * F_PITCH - 2, B + 3 * F_PITCH - 1};
+  const int offs[16] = {B + 3 * FP,     B + 3 * FP + 1, B + 2 * FP + 2, B + FP + 3,
+                        B + 3,               B - FP + 3,     B - 2 * FP + 2, B - 3 * FP + 1,
+                        B - 3 * FP,     B - 3 * FP - 1, B - 2 * FP - 2, B - FP - 3,
+                        B - 3,               B + FP - 3,     B + 2 * FP - 2, B + 3 * FP - 1};
   uint32_t r[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) r[k] = b[offs[k]];
@@ -491,43 +492,54 @@ __device__ __forceinline__ int fast_v1(const uint8_t* p /* centre in LDS */, int
 // NMS decision for the pixel whose V byte is at q: strictly greater than the 8
 // neighbours' scores, where neighbours in another cell (hasL / hasR false) or on the
 // 3-px rim (V byte 0) count as 0.  Scores are V - 1, so "score > 0" is "V >= 2".
+template <int FP>
 __device__ __forceinline__ bool fast_nms_keep(const uint8_t* q, int v, bool hasL, bool hasR) {
   // all eight loads first (the rim keeps them inside the map): one LDS round trip, not eight
-  const int u = q[-F_PITCH], d = q[F_PITCH];
-  const int l0 = q[-1], l1 = q[-F_PITCH - 1], l2 = q[F_PITCH - 1];
-  const int r0 = q[1], r1 = q[-F_PITCH + 1], r2 = q[F_PITCH + 1];
+  const int u = q[-FP], d = q[FP];
+  const int l0 = q[-1], l1 = q[-FP - 1], l2 = q[FP - 1];
+  const int r0 = q[1], r1 = q[-FP + 1], r2 = q[FP + 1];
   const int mc = max(u, d);
   const int ml = hasL ? max(l0, max(l1, l2)) : 0;
   const int mr = hasR ? max(r0, max(r1, r2)) : 0;
   return v > max(mc, max(ml, mr));
 }
 
-// floor(off / F_PITCH), and floor(n / d) for n, d < 256 with m = 65536 / d + 1 by multiplication
-// (the identity is checked over its whole range in tests/test_arith_cpu.py).
-static_assert(F_PITCH == 256, "div_pitch shifts by 8");
-__device__ __forceinline__ int div_pitch(int off) { return off >> 8; }
+// floor(off / FP) for off < 32768, and floor(n / d) for n, d < 256 with m = 65536 / d + 1, by
+// multiplication (the identities are checked over their whole ranges in tests/test_arith_cpu.py).
+template <int FP>
+__device__ __forceinline__ int div_pitch(int off) {
+  static_assert(FP == 256 || FP == 224, "div_pitch knows these two pitches");
+  return FP == 256 ? off >> 8 : (int)(((uint32_t)off * 18725u) >> 22);
+}
 __device__ __forceinline__ int div_small(int n, int m) { return (n * m) >> 16; }
 
-__global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
-                                                         const FastItem* __restrict__ items,
-                                                         uint32_t* __restrict__ cand_all,
-                                                         int* __restrict__ cand_cnt, int iniTh, int minTh,
-                                                         int lds_rows) {
-  // staged view and its V map: lds_rows rows each (the tallest cell view of the plan)
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+// the workgroup's LDS: arrays declared by the kernel (one copy, whichever pitch the body is built for)
+struct FastShared {
+  uint8_t* dyn;                  // staged view and V map
+  uint16_t (*list)[F_QCAP];      // per wavefront: quick-test survivors ...
+  uint16_t (*corner)[F_CCAP];    // ... and corners (V > t), both as the pixel's byte offset in the staged
+                                 // view (bit 15 of a survivor: test the darker ring only)
+  int* ncorner;
+  int* cnt;
+  int* vars;  // total, base, emit of the dense sweep
+};
+
+template <int FP>  // LDS row pitch of the staged view and of the V map
+__device__ __forceinline__ void fast_body(const uint8_t* __restrict__ pyr, const Plan& P, const FastItem item,
+                                          uint32_t* __restrict__ cand_all, int* __restrict__ cand_cnt, int iniTh,
+                                          int minTh, int lds_rows, const FastShared S) {
+  // staged view and its V map: lds_rows rows each (the tallest cell view of the class)
+  uint8_t* const s_dyn = S.dyn;
   uint8_t* const s_img = s_dyn;
   // the V map is indexed like the view, but only its rows 2 .. th - 3 exist (corners lie in rows
   // 3 .. th - 4, the suppression looks one row further): its first two rows would be the view's last two
-  uint8_t* const s_v = s_dyn + (lds_rows - 2) * F_PITCH;
-  // per wavefront: quick-test survivors and corners (V > t), both as the pixel's byte offset in
-  // the staged view (bit 15 of a survivor: test the darker ring only)
-  __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];
-  __shared__ uint16_t s_corner[F_THREADS / 64][F_CCAP];
-  __shared__ int s_ncorner[F_THREADS / 64];
-  __shared__ int s_cnt[F_MAXCELLS];
-  __shared__ int s_total, s_base, s_emit;
+  uint8_t* const s_v = s_dyn + (lds_rows - 2) * FP;
+  uint16_t (*const s_list)[F_QCAP] = S.list;
+  uint16_t (*const s_corner)[F_CCAP] = S.corner;
+  int* const s_ncorner = S.ncorner;
+  int* const s_cnt = S.cnt;
+  int &s_total = S.vars[0], &s_base = S.vars[1], &s_emit = S.vars[2];
 
-  const FastItem item = items[blockIdx.y];
   const int f = blockIdx.x;
   // the wave index as a scalar: loops over "rows of this wave" are then uniform for the compiler,
   // and the queue length and list addresses stay in scalar registers
@@ -563,13 +575,13 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
     }
 #pragma unroll 1
     for (int r = wave + 2; r < th - 2; r += W) {
-      *reinterpret_cast<uint32_t*>(&s_v[r * F_PITCH + 4 * lane]) = 0;
+      if (4 * lane < FP) *reinterpret_cast<uint32_t*>(&s_v[r * FP + 4 * lane]) = 0;
     }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
       const int r = wave + k * W;
       if (r < th) {
-        *reinterpret_cast<uint32_t*>(&s_img[r * F_PITCH + 4 * lane]) = v[k];
+        if (4 * lane < FP) *reinterpret_cast<uint32_t*>(&s_img[r * FP + 4 * lane]) = v[k];
       }
     }
   }
@@ -584,7 +596,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   int* const out_cnt = &cand_cnt[f * P.nlevels + item.level];
   // level coordinates (relative to the border origin) and record of the pixel at byte offset off
   auto record = [&](int off, int ey, int v) {
-    const int ex = off - ey * F_PITCH - xoff;
+    const int ex = off - ey * FP - xoff;
     const int xr = xb + 3 + ex - kBorder, yr = iniY + ey - kBorder;  // ey counts staged rows: interior row + 3
     return (uint32_t)xr | ((uint32_t)yr << kCoordBits) | ((uint32_t)(v - 1) << 24);
   };
@@ -609,7 +621,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       if (lane < n) {
         e = s_list[wave][k];
         off = e & 0x7FFF;
-        v = fast_v1(&s_img[off], t, (e & 0x8000) != 0, again);
+        v = fast_v1<FP>(&s_img[off], t, (e & 0x8000) != 0, again);
       }
       // a pixel that either polarity could make a corner (rare) goes to the queue's tail once
       // more, marked (bit 15) for the darker ring
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
           qn += __popcll(ma);
         } else if (again) {  // no room left in the queue: the second polarity right here
           bool unused;
-          v = max(v, fast_v1(&s_img[off], t, true, unused));
+          v = max(v, fast_v1<FP>(&s_img[off], t, true, unused));
         }
       }
       ncorner = __builtin_amdgcn_readfirstlane(ncorner);  // (the compiler does not see that it is the same in all lanes)
@@ -693,8 +705,8 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       }
       // byte offset of the lane's first pixel; a lane whose row lies below the view (the last step
       // of a run with several rows per step) reads the last row and never passes
-      int rowoff_next = (wave * rps + sub + 3) * F_PITCH + col4;
-      const int rowoff_last = (hi - 1 + 3) * F_PITCH + col4;
+      int rowoff_next = (wave * rps + sub + 3) * FP + col4;
+      const int rowoff_last = (hi - 1 + 3) * FP + col4;
       for (int yb = wave * rps; yb < hi; yb += (F_THREADS / 64) * rps) {
         if (yb + rps > hi) {  // uniform, and only in the last step of a run with several rows per step
           asm volatile("");   // (keeps this a branch: as selects it would cost every step four instructions)
@@ -702,18 +714,18 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         }
         const uint32_t tv01 = tv[0], tv23 = tv[1];
         const int rowoff = rowoff_next;
-        rowoff_next += (F_THREADS / 64) * rps * F_PITCH;
+        rowoff_next += (F_THREADS / 64) * rps * FP;
         // the five dwords around the lane's pixels, addressed from the topmost one (offsets that
         // fit the LDS instructions' offset fields; opaque, or the compiler re-bases them with adds)
         typedef __attribute__((address_space(3))) const uint32_t* lds_words;
-        uint32_t ra = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)s_img + rowoff - 3 * F_PITCH;
+        uint32_t ra = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)s_img + rowoff - 3 * FP;
         asm("" : "+v"(ra));
         const lds_words rw = (lds_words)(uintptr_t)ra;
         const uint32_t U = rw[0];
-        const uint32_t Lw = rw[3 * F_PITCH / 4 - 1];
-        const uint32_t C = rw[3 * F_PITCH / 4];
-        const uint32_t R = rw[3 * F_PITCH / 4 + 1];
-        const uint32_t D = rw[6 * F_PITCH / 4];
+        const uint32_t Lw = rw[3 * FP / 4 - 1];
+        const uint32_t C = rw[3 * FP / 4];
+        const uint32_t R = rw[3 * FP / 4 + 1];
+        const uint32_t D = rw[6 * FP / 4];
         // per pixel: some ring pixel pair at the compass points is brighter / darker than the centre
         // by more than t.  Nine contiguous ring pixels always contain two adjacent compass points:
         // (b0&b4)|(b4&b8)|(b8&b12)|(b12&b0) == (b0|b8)&(b4|b12), for "brighter" as for "darker", i.e.
@@ -795,13 +807,13 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       int nkeep = 0;                              // uniform
       for (int k0 = 0; k0 < ncorner; k0 += 64) {  // uniform
         const int k = k0 + lane;
-        const int off = k < ncorner ? (int)s_corner[wave][k] : 3 * F_PITCH + 4;
-        const int ey = div_pitch(off);
-        const int ex = off - ey * F_PITCH - xoff;
+        const int off = k < ncorner ? (int)s_corner[wave][k] : 3 * FP + 4;
+        const int ey = div_pitch<FP>(off);
+        const int ex = off - ey * FP - xoff;
         const int ecj = div_small(ex, wCellM), exc = ex - ecj * wCell;
         const uint8_t* q = &s_v[off];
         const int v = q[0];
-        const bool keep = k < ncorner && v >= 2 && fast_nms_keep(q, v, exc > 0, exc < wCell - 1);
+        const bool keep = k < ncorner && v >= 2 && fast_nms_keep<FP>(q, v, exc > 0, exc < wCell - 1);
         if (keep) atomicAdd(&s_cnt[ecj], 1);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) s_corner[wave][nkeep + below(m)] = (uint16_t)off;
@@ -815,7 +827,7 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
           const int k = k0 + lane;
           if (k < nkeep && wbase + k < L.cand_cap) {
             const int off = s_corner[wave][k];
-            out[wbase + k] = record(off, div_pitch(off), s_v[off]);
+            out[wbase + k] = record(off, div_pitch<FP>(off), s_v[off]);
           }
         }
       }
@@ -832,9 +844,9 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         int n = 0;
 #pragma unroll 1
         for (int y = 0; y < hi; y++) {
-          const uint8_t* q = &s_v[(y + 3) * F_PITCH + x + xoff];
+          const uint8_t* q = &s_v[(y + 3) * FP + x + xoff];
           const int v = q[0];
-          if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) n++;
+          if (v >= 2 && fast_nms_keep<FP>(q, v, xc > 0, xc < wCell - 1)) n++;
         }
         if (n) { atomicAdd(&s_cnt[cj], n); atomicAdd(&s_total, n); }
       }
@@ -845,10 +857,10 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
         const int gbase = s_base;
 #pragma unroll 1
         for (int y = 0; y < hi; y++) {
-          const int off = (y + 3) * F_PITCH + x + xoff;
+          const int off = (y + 3) * FP + x + xoff;
           const uint8_t* q = &s_v[off];
           const int v = q[0];
-          if (v >= 2 && fast_nms_keep(q, v, xc > 0, xc < wCell - 1)) {
+          if (v >= 2 && fast_nms_keep<FP>(q, v, xc > 0, xc < wCell - 1)) {
             const int slot = gbase + atomicAdd(&s_emit, 1);
             if (slot < L.cand_cap) out[slot] = record(off, y + 3, v);
           }
@@ -869,11 +881,35 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
       const int x = tid;
       if (x < wi && ((need >> div_small(x, wCellM)) & 1u)) {
 #pragma unroll 1
-        for (int y = 0; y < hi; y++) s_v[(y + 3) * F_PITCH + x + xoff] = 0;
+        for (int y = 0; y < hi; y++) s_v[(y + 3) * FP + x + xoff] = 0;
       }
     }
     __syncthreads();
   }
+}
+
+
+// Views of up to wide_rows rows are staged at a pitch of 256 bytes (runs of up to F_USEW columns);
+// taller ones at 224 (their runs are cut shorter by the host), which makes them fit the same
+// LDS budget: one launch, and as many workgroups per CU for the tall views as for the others.
+constexpr int F_PITCH_NARROW = 224;
+constexpr int F_USEW_NARROW = 208;
+static_assert(3 + F_USEW_NARROW + 6 + 3 <= F_PITCH_NARROW, "a narrow staged row must fit its pitch");
+__global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
+                                                         const FastItem* __restrict__ items,
+                                                         uint32_t* __restrict__ cand_all,
+                                                         int* __restrict__ cand_cnt, int iniTh, int minTh,
+                                                         int wide_rows, int narrow_rows) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  __shared__ uint16_t s_list[F_THREADS / 64][F_QCAP];
+  __shared__ uint16_t s_corner[F_THREADS / 64][F_CCAP];
+  __shared__ int s_ncorner[F_THREADS / 64];
+  __shared__ int s_cnt[F_MAXCELLS];
+  __shared__ int s_vars[3];
+  const FastShared S{s_dyn, s_list, s_corner, s_ncorner, s_cnt, s_vars};
+  const FastItem item = items[blockIdx.y];
+  if (P.lv[item.level].hCell + 6 <= wide_rows) fast_body<F_PITCH>(pyr, P, item, cand_all, cand_cnt, iniTh, minTh, wide_rows, S);
+  else fast_body<F_PITCH_NARROW>(pyr, P, item, cand_all, cand_cnt, iniTh, minTh, narrow_rows, S);
 }
 
 // ---------------------------------------------------------------------------
@@ -1687,34 +1723,51 @@ int pyr_tile_max_src_rows() { return PR_SROWS; }
 int pyr_tile_max_src_bytes() { return PR_MAXPITCH; }
 // The tallest cell view with which six workgroups of fast_kernel fit a CU's LDS (160 KB, handed
 // out in 512-byte units on gfx950; five fit with the tallest view the kernel takes, and the sixth
-// is worth a tenth of the kernel's time).
-int fast_rows_dense() {
-  static const int rows = [] {
+// is worth a few percent of the kernel's time): at the wide pitch, and at the narrow one.
+static long fast_lds_budget() {
+  static const long budget = [] {
     hipFuncAttributes a{};
-    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(fast_kernel)) != hipSuccess) return 0;
-    const long budget = (160 * 1024 / 6) / 512 * 512 - (long)a.sharedSizeBytes;  // dynamic LDS a workgroup may take
-    const long r = (budget / F_PITCH + 4) / 2;
-    return budget < 10 * F_PITCH ? 0 : (int)(r < F_MAXH ? r : F_MAXH);
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(fast_kernel)) != hipSuccess) return 0L;
+    return (long)((160 * 1024 / 6) / 512 * 512) - (long)a.sharedSizeBytes;  // dynamic LDS a workgroup may take
   }();
-  return rows;
+  return budget;
 }
-// items [0, nshort) have views of at most fast_rows_dense() rows (one launch with that LDS footprint),
-// the others follow in a launch sized for the tallest view; nshort = 0: one launch for all
-void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, int nshort, uint32_t* cand,
+static int fast_rows_for(long budget, int pitch) {
+  const long r = (budget / pitch + 4) / 2;
+  return budget < 10 * pitch ? 0 : (int)(r < F_MAXH ? r : F_MAXH);
+}
+int fast_rows_dense() { return fast_rows_for(fast_lds_budget(), F_PITCH); }
+int fast_rows_narrow() { return fast_rows_for(fast_lds_budget(), F_PITCH_NARROW); }
+int fast_use_width_narrow() { return F_USEW_NARROW; }
+// items [0, ntall) have views taller than fast_rows_dense() rows and are cut for the narrow pitch
+// (see fast_kernel; they come first: the longest workgroups should not be the last to start), the
+// others follow.  ntall < 0: one launch, everything at the wide pitch with room for the tallest view
+// (launches of a few frames: occupancy does not matter).
+void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, int ntall, uint32_t* cand,
                  int* cand_cnt, int iniTh, int minTh, int nframes, hipStream_t st) {
   int rows = 7;
   for (int l = 0; l < P.nlevels; l++) rows = max(rows, P.lv[l].hCell + 6);
   rows = min(rows, F_MAXH);
-  if (nshort > 0 && rows > fast_rows_dense()) {
-    const int r = fast_rows_dense();
-    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nshort), dim3(F_THREADS), (2 * (size_t)r - 4) * F_PITCH, st, pyr, P, items,
-                       cand, cand_cnt, iniTh, minTh, r);
-    items += nshort;
-    nitems -= nshort;
+  const int dense = fast_rows_dense();
+  if (ntall >= 0 && rows > dense && rows <= fast_rows_narrow()) {
+    // one launch, two kinds of workgroup, the same LDS footprint
+    const size_t lds = max((2 * (size_t)dense - 4) * F_PITCH, (2 * (size_t)rows - 4) * F_PITCH_NARROW);
+    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), lds, st, pyr, P, items, cand, cand_cnt, iniTh,
+                       minTh, dense, rows);
+    return;
+  }
+  if (ntall > 0 && ntall < nitems && rows > dense) {
+    // views too tall even for the narrow pitch: those with room for the tallest, then the others
+    // with the small footprint
+    hipLaunchKernelGGL(fast_kernel, dim3(nframes, ntall), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, P, items,
+                       cand, cand_cnt, iniTh, minTh, rows, rows);
+    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems - ntall), dim3(F_THREADS), (2 * (size_t)dense - 4) * F_PITCH, st, pyr,
+                       P, items + ntall, cand, cand_cnt, iniTh, minTh, dense, dense);
+    return;
   }
   if (nitems > 0)
     hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, P, items,
-                       cand, cand_cnt, iniTh, minTh, rows);
+                       cand, cand_cnt, iniTh, minTh, rows, rows);
 }
 template <int MAXS, int THREADS>
 static hipError_t launch_octree_t(const uint32_t* cand, const int* cand_cnt, uint32_t* pnode, uint32_t* sel,

@@ -25,3 +25,11 @@ def test_umulhi_division_is_exact_while_the_product_fits():
         got = np.array([(int(x) * m) >> 32 for x in t[:: max(1, len(t) // 3000)]])
         want = np.array([int(x) // n for x in t[:: max(1, len(t) // 3000)]])
         assert np.array_equal(got, want), n
+
+
+def test_division_by_the_narrow_lds_pitch():
+    """FAST: a byte offset in a view staged at 224 bytes per row -> its row,
+    off / 224 == (off * 18725) >> 22 for every offset a 15-bit queue entry can hold."""
+    off = np.arange(32768, dtype=np.int64)
+    assert np.array_equal((off * 18725) >> 22, off // 224)
+    assert int(off[-1]) * 18725 < 2 ** 32
