@@ -11,8 +11,7 @@ rows = [r for r in csv.reader(open(fn))]
 out = open('profiles/%s_kernel_stats.csv' % tag, 'w')
 out.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-frames 0 --host-reps 0 --knn-reps 3 "
           "(256 frames per launch; 1M x 1M kNN-2: knn2_mfma_kernel x3 + warm-up, knn2_kernel x1; MI355X). "
-          "fast_kernel takes two launches per step (cell views of up to 41 rows, and the taller ones): its stage time is twice the average; "
-          "pyr_resize_tile_kernel takes seven (levels 1-7)\n")
+          "pyr_resize_tile_kernel takes seven launches per step (levels 1-7)\n")
 w = csv.writer(out); w.writerow(rows[0])
 for r in rows[1:]:
     if 'orbhip' in r[0]:
