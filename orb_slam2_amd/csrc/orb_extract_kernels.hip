@@ -28,7 +28,7 @@ __device__ __forceinline__ int refl101(int i, int n) {
 // numbered first (row by row), the others after them, so that all but one wavefront hold a
 // single kind and none runs both paths.
 // ---------------------------------------------------------------------------
-constexpr int L0_PIECES = 2;  // 16-byte pieces per thread of the level-0 copy
+constexpr int L0_PIECES = 4;  // 16-byte pieces per thread of the level-0 copy (2: 1 % slower, 8: the same)
 struct L0Map {
   int ca, ni;      // pieces [ca, ca + ni) of a row are interior (ni = 0: none)
   int nb;          // the other pieces of a row
