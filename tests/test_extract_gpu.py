@@ -156,6 +156,37 @@ def test_low_texture_uses_min_threshold(oracle):
     check_stages(ex, ref, 8)
 
 
+@pytest.mark.parametrize("kind", ["noise", "salt", "checker"])
+def test_dense_corners_take_the_overflow_paths(oracle, kind):
+    """Images on which nearly every pixel passes FAST's quick test and a large part are corners:
+    the per-wavefront corner lists overflow (dense sweep of the score map), queues re-queue
+    both polarities, levels hold far more candidates than the quad-tree keeps in registers.
+    One frame alone and the same frame in a batch (other launch shapes), stage by stage."""
+    from orb_slam2_amd import ORBextractor
+    rng = np.random.default_rng(5)
+    rows, cols = 240, 416
+    if kind == "noise":
+        img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    elif kind == "salt":
+        img = np.full((rows, cols), 128, np.uint8)
+        m = rng.random((rows, cols)) < 0.08
+        img[m] = rng.choice(np.array([0, 255], np.uint8), int(m.sum()))
+    else:
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        img = (((yy // 5 + xx // 5) & 1) * 200 + 20 + rng.integers(0, 9, (rows, cols))).astype(np.uint8)
+    ex = ORBextractor(1500, 1.2, 8, 20, 7)
+    ref = oracle.Extractor(1500, 1.2, 8, 20, 7)
+    kps, desc = ex(img)
+    rk, rd = ref(img)
+    assert len(rk) > 500
+    check_against(kps, desc, rk, rd)
+    check_stages(ex, ref, 8)
+    bk, bd = ex.extract_batch(np.repeat(img[None], 10, 0))
+    for f in (0, 9):
+        check_against(bk[f], bd[f], rk, rd)
+    check_stages(ex, ref, 8, frame=9)
+
+
 def test_constant_and_empty_images():
     from orb_slam2_amd import ORBextractor
     ex = ORBextractor(500, 1.2, 8, 20, 7)
