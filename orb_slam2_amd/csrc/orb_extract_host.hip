@@ -413,10 +413,11 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
       ti.xr_off = (int)ranges.size(); ranges.insert(ranges.end(), xr.begin(), xr.end());
       for (int v = 0; v < 2; v++) {
         const int TR = TRv[v];
-        ti.ngy[v] = (L.h + 2 * kEdge + TR - 1) / TR;
+        // tiles of the level's own rows (the frame rows are stored as copies of their mirror images)
+        ti.ngy[v] = (L.h + TR - 1) / TR;
         std::vector<int2> yr(ti.ngy[v], make_int2(1 << 30, -1));
-        for (int r = 0; r < L.h + 2 * kEdge; r++) {
-          const YTab& t = ytab[L.ytab_off + refl(r - kEdge, L.h)];
+        for (int r = 0; r < L.h; r++) {
+          const YTab& t = ytab[L.ytab_off + r];
           int2& q = yr[r / TR];
           q.x = std::min(q.x, (int)std::min(t.sy0, t.sy1)); q.y = std::max(q.y, (int)std::max(t.sy0, t.sy1));
         }

@@ -234,10 +234,12 @@ __device__ __forceinline__ void pr_tile(uint8_t* __restrict__ pyr, unsigned long
           *reinterpret_cast<const uint4*>(src + (size_t)r * Ls.pitch + 16 * c);
   // the rows' vertical taps: lane i of every wavefront fetches those of the tile's row i now (the
   // loop below reads them with v_readlane instead of waiting for a scalar load per row)
+  // (tiles cover the level's own rows; the rows of the reflected frame above and below are copies
+  // of rows 1 .. 19 and h - 20 .. h - 2 and are stored along with those)
   const int rbeg = gy * tile_rows;
   unsigned long long ytl = 0;
   if ((tid & 63) < tile_rows)
-    ytl = *reinterpret_cast<const unsigned long long*>(&yt[refl101(min(rbeg + (tid & 63), Ld.h + 2 * kEdge - 1) - kEdge, Ld.h)]);
+    ytl = *reinterpret_cast<const unsigned long long*>(&yt[min(rbeg + (tid & 63), Ld.h - 1)]);
   __syncthreads();
   const int c = gx * PR_TC + 4 * tid;
   if (c >= Ld.pitch) return;
@@ -262,7 +264,7 @@ __device__ __forceinline__ void pr_tile(uint8_t* __restrict__ pyr, unsigned long
   uint32_t hprev[4] = {0, 0, 0, 0};
   int prev_row = -1;  // source row whose horizontal result is in hprev
   uint8_t* dst = pyr + (size_t)f * slab + Ld.off + c;
-  const int rend = min(gy * tile_rows + tile_rows, Ld.h + 2 * kEdge);
+  const int rend = min(gy * tile_rows + tile_rows, Ld.h);
   for (int r = rbeg; r < rend; r++) {
     const uint32_t ylo = __builtin_amdgcn_readlane((uint32_t)ytl, r - rbeg);
     const uint32_t yhi = __builtin_amdgcn_readlane((uint32_t)(ytl >> 32), r - rbeg);
@@ -295,7 +297,10 @@ __device__ __forceinline__ void pr_tile(uint8_t* __restrict__ pyr, unsigned long
       hprev[k] = h1[k];
     }
     prev_row = s1;
-    *reinterpret_cast<uint32_t*>(dst + (size_t)r * Ld.pitch) = out;
+    *reinterpret_cast<uint32_t*>(dst + (size_t)(r + kEdge) * Ld.pitch) = out;
+    const int up = kEdge - r, down = kEdge + 2 * (Ld.h - 1) - r;  // the row's mirror images in the frame (uniform)
+    if (r >= 1 && up >= 0) *reinterpret_cast<uint32_t*>(dst + (size_t)up * Ld.pitch) = out;
+    if (r <= Ld.h - 2 && down < Ld.h + 2 * kEdge) *reinterpret_cast<uint32_t*>(dst + (size_t)down * Ld.pitch) = out;
   }
 }
 
@@ -407,13 +412,17 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_dual_kernel(
   // level l + 1: the tile's rows from them
   const int c = 4 * tid;
   if (c >= L2.pitch) return;
-  const int rbeg = gy * tile_rows, rend = min(rbeg + tile_rows, L2.h + 2 * kEdge);
+  const int rbeg = gy * tile_rows, rend = min(rbeg + tile_rows, L2.h);
   unsigned long long y2l = 0;
-  if (lane < rend - rbeg)
-    y2l = *reinterpret_cast<const unsigned long long*>(&yt[L2.ytab_off + refl101(rbeg + lane - kEdge, L2.h)]);
+  if (lane < rend - rbeg) y2l = *reinterpret_cast<const unsigned long long*>(&yt[L2.ytab_off + rbeg + lane]);
   uint8_t* dst = pyr + (size_t)f * slab + L2.off + c;
-  pass(s_b, pitchB, Y2.x, *reinterpret_cast<const uint4*>(&xtp2[c]), y2l, rend - rbeg,
-       [&](int i, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + (size_t)(rbeg + i) * L2.pitch) = v; });
+  pass(s_b, pitchB, Y2.x, *reinterpret_cast<const uint4*>(&xtp2[c]), y2l, rend - rbeg, [&](int i, uint32_t v) {
+    const int r = rbeg + i;
+    *reinterpret_cast<uint32_t*>(dst + (size_t)(r + kEdge) * L2.pitch) = v;
+    const int up = kEdge - r, down = kEdge + 2 * (L2.h - 1) - r;
+    if (r >= 1 && up >= 0) *reinterpret_cast<uint32_t*>(dst + (size_t)up * L2.pitch) = v;
+    if (r <= L2.h - 2 && down < L2.h + 2 * kEdge) *reinterpret_cast<uint32_t*>(dst + (size_t)down * L2.pitch) = v;
+  });
 }
 
 // ---------------------------------------------------------------------------
