@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ p
 }
 
 // Tiled form of the resize for scale factors up to about 1.45: a workgroup produces
-// PR_TR padded rows x PR_TC slab columns.  The source rows it needs are staged in LDS
+// PR_TR rows of the level x PR_TC slab columns (the frame's columns with them, at their
+// mirrored coordinates; the frame's rows as copies).  The source rows it needs are staged in LDS
 // with 16-byte loads; a thread owns 4 adjacent output columns (one dword store per
 // row), reads its taps from LDS and reuses the horizontal result of a source row
 // when the next output row starts on it.  xtp[] holds, per SLAB column, the source
