@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -58,69 +60,92 @@ using namespace orbhip;
 
 // A few host threads that share the packing of a batch into / out of the pinned staging
 // buffers: one thread copies at about 10 GB/s, far less than the DMA engines and the kernels
-// take.  parallel_for(n, f) runs f(0) .. f(n - 1) on the workers and the caller, and returns
-// when all are done.
+// take.  submit(n, f) queues f(0) .. f(n - 1) and returns at once; the jobs are worked on in the
+// order they were queued.  wait(job) returns when that job's items are done, wait_all() when
+// every queued item is; both lend the calling thread to the queue while they wait.
+// parallel_for(n, f) is submit + wait.  One thread at a time may submit and wait.
 class HostCopyPool {
  public:
+  struct Job {
+    std::function<void(int)> f;
+    int count = 0, next = 0, left = 0;
+  };
+  using JobRef = std::shared_ptr<Job>;
+
   explicit HostCopyPool(int workers) {
     for (int i = 0; i < workers; i++) threads_.emplace_back([this] { run(); });
   }
   ~HostCopyPool() {
+    wait_all();
     { std::lock_guard<std::mutex> l(m_); stop_ = true; }
     cv_.notify_all();
     for (auto& t : threads_) t.join();
   }
-  void parallel_for(int n, const std::function<void(int)>& f) {
-    if (n <= 0) return;
-    uint64_t gen;
-    {
-      std::lock_guard<std::mutex> l(m_);
-      job_ = &f; count_ = n; next_ = 0; left_ = n; gen = ++gen_;
-    }
+  JobRef submit(int n, std::function<void(int)> f) {
+    JobRef j = std::make_shared<Job>();
+    if (n <= 0) return j;
+    j->f = std::move(f); j->count = n; j->left = n;
+    { std::lock_guard<std::mutex> l(m_); queue_.push_back(j); pending_ += n; }
     cv_.notify_all();
-    work(gen);
-    std::unique_lock<std::mutex> l(m_);
-    done_.wait(l, [this] { return left_ == 0; });
-    job_ = nullptr;
+    return j;
   }
+  void wait(const JobRef& j) { help_until([&] { return j->left == 0; }); }
+  void wait_all() { help_until([&] { return pending_ == 0; }); }
+  void parallel_for(int n, const std::function<void(int)>& f) { wait(submit(n, f)); }
 
  private:
-  // items are handed out under the lock and only to threads working on generation `gen`, so a
-  // worker that wakes up late can never take an item of a later call
-  void work(uint64_t gen) {
-    for (;;) {
-      const std::function<void(int)>* f;
-      int i;
-      {
-        std::lock_guard<std::mutex> l(m_);
-        if (gen_ != gen || job_ == nullptr || next_ >= count_) return;
-        i = next_++;
-        f = job_;
+  // (under the lock) the next item of the oldest job that still has items to hand out
+  bool take(JobRef& j, int& i) {
+    while (!queue_.empty() && queue_.front()->next >= queue_.front()->count) queue_.pop_front();
+    if (queue_.empty()) return false;
+    j = queue_.front();
+    i = j->next++;
+    return true;
+  }
+  // (under the lock) one item has been worked off
+  void finished(const JobRef& j) {
+    --pending_;
+    if (--j->left == 0 || pending_ == 0) done_.notify_all();
+  }
+  template <typename Pred>
+  void help_until(Pred ready) {
+    std::unique_lock<std::mutex> l(m_);
+    while (!ready()) {
+      JobRef j; int i;
+      if (take(j, i)) {
+        l.unlock();
+        j->f(i);
+        l.lock();
+        finished(j);
+      } else {
+        done_.wait(l);
       }
-      (*f)(i);
-      std::lock_guard<std::mutex> l(m_);
-      if (--left_ == 0) done_.notify_all();
     }
   }
   void run() {
-    uint64_t seen = 0;
+    std::unique_lock<std::mutex> l(m_);
     for (;;) {
-      {
-        std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&] { return stop_ || (gen_ != seen && job_ != nullptr); });
-        if (stop_) return;
-        seen = gen_;
-      }
-      work(seen);
+      JobRef j; int i = 0;
+      cv_.wait(l, [&] { return stop_ || take(j, i); });
+      if (!j) return;  // stop_, and nothing taken
+      l.unlock();
+      j->f(i);
+      l.lock();
+      finished(j);
     }
   }
   std::vector<std::thread> threads_;
   std::mutex m_;
   std::condition_variable cv_, done_;
-  const std::function<void(int)>* job_ = nullptr;
-  int count_ = 0, next_ = 0, left_ = 0;
-  uint64_t gen_ = 0;
+  std::deque<JobRef> queue_;
+  long pending_ = 0;  // items queued or being worked on, over all jobs
   bool stop_ = false;
+};
+
+// waits for everything a call has queued before the call's locals go away, whichever way it returns
+struct PoolDrain {
+  HostCopyPool* pool;
+  ~PoolDrain() { if (pool) pool->wait_all(); }
 };
 
 struct OrbExtractor {
@@ -132,6 +157,9 @@ struct OrbExtractor {
   int taps[4];  // first four taps of the 7-tap blur kernel (it is symmetric), 8.8 fixed point
   int gray[4];  // cvtColor weights R, G, B and their shift
   hipStream_t stream = nullptr;
+  // host-buffer batches in pieces: uploads and downloads on streams of their own, beside the kernels
+  hipStream_t up = nullptr, down = nullptr;
+  std::vector<hipEvent_t> pipe_ev;
 
   // plan for the current image size
   Plan plan{};
@@ -198,8 +226,16 @@ namespace {
 
 constexpr int kSmallBatchFrames = 8;               // up to this many frames a launch is cut into more, smaller workgroups
 constexpr int kFewFrames = 4;                       // up to this many frames FAST takes shorter runs of cells
+constexpr int kPipeMinFrames = 64;                  // host-buffer batches from this size on go through in pieces
+constexpr int kPipePieces = 8;                      // ... at most this many
 constexpr int kGraphMaxFrames = 8;                 // batches up to this size replay a captured graph
-constexpr int kPoolThreads = 8;                    // host threads that pack a large batch (the caller is one)
+constexpr int kPoolThreads = 12;                   // host threads that pack a large batch (the caller is one)
+// ORBHIP_HOST_THREADS in the environment overrides that count (1 .. 64) for pools made afterwards
+static int pool_threads() {
+  const char* e = getenv("ORBHIP_HOST_THREADS");
+  const int n = e ? atoi(e) : 0;
+  return n >= 1 && n <= 64 ? n : kPoolThreads;
+}
 constexpr size_t kPoolMinBytes = (size_t)4 << 20;  // smaller batches are packed by the caller alone
 
 void free_plan_buffers(OrbExtractor* h) {
@@ -473,9 +509,18 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   return ORBHIP_OK;
 }
 
+// frame0: the batch's first frame takes slot frame0 of the handle's internal buffers (a host-buffer
+// batch that is processed in pieces keeps every frame's intermediate results)
 int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride, size_t frame_stride, int max_kp,
-            OrbKeyPoint* d_kps, uint8_t* d_desc, int* d_nout, hipStream_t st) {
+            OrbKeyPoint* d_kps, uint8_t* d_desc, int* d_nout, hipStream_t st, int frame0 = 0) {
   const Plan& P = h->plan;
+  uint8_t* const b_pyr = h->d_pyr + (size_t)frame0 * P.slab;
+  uint8_t* const b_blur = h->d_blur + (size_t)frame0 * P.slab;
+  uint32_t* const b_cand = h->d_cand + (size_t)frame0 * P.cand_total;
+  uint32_t* const b_pnode = h->d_pnode + (size_t)frame0 * P.cand_total;
+  uint32_t* const b_sel = h->d_sel + (size_t)frame0 * P.sel_total;
+  int* const b_cand_cnt = h->d_cand_cnt + (size_t)frame0 * P.nlevels;
+  int* const b_sel_cnt = h->d_sel_cnt + (size_t)frame0 * P.nlevels;
   const bool prof = h->profiling;
   hipEvent_t* ev = nullptr;
   if (prof) {
@@ -489,14 +534,14 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[0], st));
   // (the level-0 kernel also clears the frames' candidate counters)
-  if (h->channels == 1) launch_pyr_level0(d_images, stride, frame_stride, h->d_pyr, P, h->d_cand_cnt, nframes, st);
-  else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->gray, h->d_pyr, P, h->d_cand_cnt, nframes, st);
+  if (h->channels == 1) launch_pyr_level0(d_images, stride, frame_stride, b_pyr, P, b_cand_cnt, nframes, st);
+  else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->gray, b_pyr, P, b_cand_cnt, nframes, st);
   for (int l = 1; l < P.nlevels; l++) {
     const OrbExtractor::TileInfo& ti = h->tile[l];
     if (nframes <= kSmallBatchFrames && h->pair[l].ok) {
       const OrbExtractor::TileInfo& t2 = h->tile[l + 1];
       const OrbExtractor::PairInfo& pi = h->pair[l];
-      launch_pyr_resize_dual(h->d_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_xtp + t2.xtp_off, h->d_ytab,
+      launch_pyr_resize_dual(b_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_xtp + t2.xtp_off, h->d_ytab,
                              h->d_ranges + ti.xr_off, ti.ngx, h->d_ranges + ti.yr_off[1], ti.ngy[1],
                              h->d_ranges + t2.yr_off[1], t2.ngy[1], pyr_tile_rows_small(), ti.src_pitch, pi.spitch0,
                              pi.pitchB, pi.offB, pi.lds, nframes, st);
@@ -505,32 +550,32 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
     }
     if (ti.ok) {
       const int v = nframes <= kSmallBatchFrames ? 1 : 0;
-      launch_pyr_resize_tile(h->d_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off, ti.ngx,
+      launch_pyr_resize_tile(b_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off, ti.ngx,
                              h->d_ranges + ti.yr_off[v], ti.ngy[v], v ? pyr_tile_rows_small() : pyr_tile_rows(),
                              ti.src_rows[v], ti.src_pitch, nframes, st);
     }
     else
-      launch_pyr_resize(h->d_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
+      launch_pyr_resize(b_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[1], st));
   {
     const int n_all = (int)h->fast_items.size(), n_batch = n_all - h->fast_items_few;
     if (nframes <= kFewFrames)
-      launch_fast(h->d_pyr, P, h->d_fast_items + n_batch, h->fast_items_few, -1, h->d_cand, h->d_cand_cnt, h->iniTh, h->minTh,
+      launch_fast(b_pyr, P, h->d_fast_items + n_batch, h->fast_items_few, -1, b_cand, b_cand_cnt, h->iniTh, h->minTh,
                   nframes, st);
     else
-      launch_fast(h->d_pyr, P, h->d_fast_items, n_batch, nframes <= kSmallBatchFrames ? -1 : h->fast_items_tall, h->d_cand,
-                  h->d_cand_cnt, h->iniTh, h->minTh, nframes, st);
+      launch_fast(b_pyr, P, h->d_fast_items, n_batch, nframes <= kSmallBatchFrames ? -1 : h->fast_items_tall, b_cand,
+                  b_cand_cnt, h->iniTh, h->minTh, nframes, st);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));
-  ORB_HIP_CHECK(launch_octree(h->d_cand, h->d_cand_cnt, h->d_pnode, h->d_sel, h->d_sel_cnt, P, h->ot_slots, nframes, st));
+  ORB_HIP_CHECK(launch_octree(b_cand, b_cand_cnt, b_pnode, b_sel, b_sel_cnt, P, h->ot_slots, nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[3], st));
-  launch_blur(h->d_pyr, h->d_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
+  launch_blur(b_pyr, b_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[4], st));
-  launch_orient_desc(h->d_pyr, h->d_blur, h->d_sel, h->d_sel_cnt, P, d_kps, d_desc, d_nout, max_kp, nframes, st);
+  launch_orient_desc(b_pyr, b_blur, b_sel, b_sel_cnt, P, d_kps, d_desc, d_nout, max_kp, nframes, st);
   if (prof) { ORB_HIP_CHECK(hipEventRecord(ev[5], st)); h->prof_calls++; }
   ORB_HIP_CHECK(hipGetLastError());
-  h->last_frames = nframes;
+  h->last_frames = frame0 + nframes;
   return ORBHIP_OK;
 }
 
@@ -638,6 +683,9 @@ void orb_extractor_destroy(OrbExtractor* h) {
   delete h->pool;
   for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
   if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  for (hipEvent_t e : h->pipe_ev) if (e) hipEventDestroy(e);
+  if (h->up) hipStreamDestroy(h->up);
+  if (h->down) hipStreamDestroy(h->down);
   hipStreamDestroy(h->stream);
   delete h;
 }
@@ -791,6 +839,96 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
     else for (int r = 0; r < rows; r++) memcpy(dst + (size_t)r * row_bytes, src + (size_t)r * stride, row_bytes);
   };
   const bool small = n_frames <= kGraphMaxFrames && img_bytes < kPoolMinBytes;
+  // Large batches go through in pieces: while the kernels work on one piece, the next is packed
+  // and uploaded and the results of the one before come back, each on a stream of its own, so
+  // that the call takes about as long as the slowest of the three instead of their sum.
+  const bool pieces = n_frames >= kPipeMinFrames && !h->profiling;
+  if (pieces) {
+    const size_t out_bytes_p = need * (sizeof(OrbKeyPoint) + 32) + sizeof(int) * (size_t)n_frames;
+    if (out_bytes_p > h->h_out_bytes) {
+      ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (h->h_out) hipHostFree(h->h_out);
+      h->h_out = nullptr; h->h_out_bytes = 0;
+      ORB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_out), out_bytes_p, hipHostMallocDefault));
+      h->h_out_bytes = out_bytes_p;
+    }
+    if (!h->up) ORB_HIP_CHECK(hipStreamCreateWithFlags(&h->up, hipStreamNonBlocking));
+    if (!h->down) ORB_HIP_CHECK(hipStreamCreateWithFlags(&h->down, hipStreamNonBlocking));
+    const int npieces = std::min(kPipePieces, n_frames / 16);
+    while ((int)h->pipe_ev.size() < 3 * npieces) {
+      hipEvent_t e;
+      ORB_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->pipe_ev.push_back(e);
+    }
+    if (!h->pool) h->pool = new HostCopyPool(pool_threads() - 1);
+    uint8_t* const sp_desc = h->h_out;
+    OrbKeyPoint* const sp_kps = reinterpret_cast<OrbKeyPoint*>(h->h_out + need * 32);
+    int* const sp_n = reinterpret_cast<int*>(h->h_out + need * (32 + sizeof(OrbKeyPoint)));
+    // the streams of this call start after whatever the handle's stream still has to do
+    ORB_HIP_CHECK(hipStreamSynchronize(st));
+    int status = ORBHIP_OK;
+    auto piece = [&](int p, int& f0, int& fn) {
+      f0 = (int)((long long)n_frames * p / npieces);
+      fn = (int)((long long)n_frames * (p + 1) / npieces) - f0;
+    };
+    // The host threads pack the pieces one after the other from the start of the call; this
+    // thread only waits for a piece, queues its upload, kernels and download, and hands the
+    // unpacking of a finished piece back to the host threads.
+    PoolDrain drain{h->pool};
+    std::vector<HostCopyPool::JobRef> packed(npieces);
+    for (int p = 0; p < npieces; p++) {
+      int f0, fn;
+      piece(p, f0, fn);
+      packed[p] = h->pool->submit(fn, [&pack, f0](int i) { pack(f0 + i); });
+    }
+    // waits for piece p's download and queues the copy of the valid part of its frames to the
+    // caller's arrays
+    auto deliver = [&](int p) -> int {
+      int f0, fn;
+      piece(p, f0, fn);
+      hipError_t e = hipEventSynchronize(h->pipe_ev[2 * npieces + p]);
+      if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+      int r = ORBHIP_OK;
+      for (int k = f0; k < f0 + fn; k++) {
+        n_out[k] = sp_n[k];
+        if (n_out[k] > max_kp) { set_error("max_kp too small: a frame produced " + std::to_string(n_out[k]) + " keypoints"); r = ORBHIP_ERR_CAPACITY; }
+      }
+      h->pool->submit(fn, [=](int i) {
+        const int k = f0 + i, n = std::min(sp_n[k], max_kp);
+        if (n > 0) {
+          memcpy(keypoints + (size_t)k * max_kp, sp_kps + (size_t)k * max_kp, sizeof(OrbKeyPoint) * n);
+          memcpy(descriptors + (size_t)k * max_kp * 32, sp_desc + (size_t)k * max_kp * 32, 32 * (size_t)n);
+        }
+      });
+      return r;
+    };
+    for (int p = 0; p < npieces; p++) {
+      int f0, fn;
+      piece(p, f0, fn);
+      h->pool->wait(packed[p]);
+      ORB_HIP_CHECK(hipMemcpyAsync(h->d_img + (size_t)f0 * frame_bytes, h->h_img + (size_t)f0 * frame_bytes,
+                                   (size_t)fn * frame_bytes, hipMemcpyHostToDevice, h->up));
+      ORB_HIP_CHECK(hipEventRecord(h->pipe_ev[2 * p], h->up));
+      ORB_HIP_CHECK(hipStreamWaitEvent(st, h->pipe_ev[2 * p], 0));
+      rc = enqueue(h, fn, h->d_img + (size_t)f0 * frame_bytes, row_bytes, frame_bytes, max_kp, h->d_kps + (size_t)f0 * max_kp,
+                   h->d_desc + (size_t)f0 * max_kp * 32, h->d_nout + f0, st, f0);
+      if (rc != ORBHIP_OK) { hipDeviceSynchronize(); return rc; }
+      ORB_HIP_CHECK(hipEventRecord(h->pipe_ev[2 * p + 1], st));
+      ORB_HIP_CHECK(hipStreamWaitEvent(h->down, h->pipe_ev[2 * p + 1], 0));
+      const size_t k0 = (size_t)f0 * max_kp, kn = (size_t)fn * max_kp;
+      ORB_HIP_CHECK(hipMemcpyAsync(sp_desc + k0 * 32, h->d_desc + k0 * 32, kn * 32, hipMemcpyDeviceToHost, h->down));
+      ORB_HIP_CHECK(hipMemcpyAsync(sp_kps + k0, h->d_kps + k0, kn * sizeof(OrbKeyPoint), hipMemcpyDeviceToHost, h->down));
+      ORB_HIP_CHECK(hipMemcpyAsync(sp_n + f0, h->d_nout + f0, sizeof(int) * fn, hipMemcpyDeviceToHost, h->down));
+      ORB_HIP_CHECK(hipEventRecord(h->pipe_ev[2 * npieces + p], h->down));
+      // the results of the piece before the last one enqueued are back by now, or soon
+      if (p >= 2) { const int rc2 = deliver(p - 2); if (rc2 != ORBHIP_OK) status = rc2; }
+    }
+    for (int p = std::max(0, npieces - 2); p < npieces; p++) { const int rc2 = deliver(p); if (rc2 != ORBHIP_OK) status = rc2; }
+    h->pool->wait_all();
+    if (status == ORBHIP_ERR_HIP) return status;
+    ORB_HIP_CHECK(hipStreamSynchronize(st));
+    return status;
+  }
   if (small) {
     for (int k = 0; k < n_frames; k++) pack(k);  // the upload is part of the replayed graph
   } else if (n_frames < 4 || img_bytes < kPoolMinBytes) {
@@ -799,7 +937,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   } else {
     // large batches: the packing is shared by a few threads, and the DMA of one chunk of frames
     // runs while the next chunk is packed
-    if (!h->pool) h->pool = new HostCopyPool(kPoolThreads - 1);
+    if (!h->pool) h->pool = new HostCopyPool(pool_threads() - 1);
     const int chunk = std::max(kPoolThreads, (int)((size_t)(8u << 20) / frame_bytes));
     for (int k0 = 0; k0 < n_frames; k0 += chunk) {
       const int kn = std::min(chunk, n_frames - k0);

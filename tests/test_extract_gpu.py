@@ -302,6 +302,53 @@ def test_large_batch_equals_small_batches(oracle):
         check_against(bk[f], bd[f], rk, rd)
 
 
+def test_host_batch_in_pieces(oracle):
+    """Host-buffer batches of 64 frames and more go through in pieces, each with an upload, its
+    kernels and a download of its own: strided host images (rows and frames with padding), the
+    64-frame threshold, the stages of frames in different pieces, a capacity too small for the
+    results, and a smaller batch on the same handle afterwards."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd._lib import ERR_CAPACITY, KP_DTYPE, lib
+    from orb_slam2_amd.synth import synth_sequence
+    L = lib()
+    rows, cols, n = 150, 203, 71
+    seq = synth_sequence(rows, cols, n, seed=23, step=1)
+    stride, fstride = cols + 13, (rows + 3) * (cols + 13) + 5
+    buf = np.full(n * fstride, 77, np.uint8)
+    for k in range(n):
+        for r in range(rows):
+            o = k * fstride + r * stride
+            buf[o:o + cols] = seq[k, r]
+    ex = ORBextractor(250, 1.2, 5, 20, 7)
+    ref = oracle.Extractor(250, 1.2, 5, 20, 7)
+    cap = ex.max_keypoints(rows, cols)
+    for m in (n, 64, 63):
+        kps = np.zeros((m, cap), KP_DTYPE)
+        desc = np.zeros((m, cap, 32), np.uint8)
+        nout = np.full(m, -1, np.int32)
+        rc = L.orb_extract_batch(ex._h, m, buf.ctypes.data, rows, cols, stride, fstride, cap,
+                                 kps.ctypes.data, desc.ctypes.data, nout.ctypes.data)
+        assert rc == 0
+        ex._frames = m
+        ck, cd = ORBextractor(250, 1.2, 5, 20, 7).extract_batch(seq[:m][::-1])  # contiguous, another order
+        for f in range(m):
+            assert np.array_equal(kps[f, :nout[f]], ck[m - 1 - f]) and np.array_equal(desc[f, :nout[f]], cd[m - 1 - f]), (m, f)
+        for f in (0, m // 2, m - 1):
+            rk, rd = ref(seq[f])
+            check_against(kps[f, :nout[f]], desc[f, :nout[f]], rk, rd)
+            check_stages(ex, ref, 5, frame=f)
+    # a capacity below what a frame produces: the counts still come back, with the error code
+    small = int(nout.min()) - 1
+    kps = np.zeros((n, small), KP_DTYPE)
+    desc = np.zeros((n, small, 32), np.uint8)
+    n2 = np.zeros(n, np.int32)
+    rc = L.orb_extract_batch(ex._h, n, buf.ctypes.data, rows, cols, stride, fstride, small,
+                             kps.ctypes.data, desc.ctypes.data, n2.ctypes.data)
+    assert rc == ERR_CAPACITY and (n2 > small).all()
+    bk, _ = ex.extract_batch(seq)
+    assert [len(k) for k in bk] == list(n2)
+
+
 @pytest.mark.parametrize("rows,cols,nlevels,scale", [(376, 1241, 8, 1.2), (480, 640, 8, 1.2), (211, 333, 5, 1.3),
                                                     (1080, 1920, 8, 1.2)])
 def test_batch_stages_match_oracle(oracle, rows, cols, nlevels, scale):
