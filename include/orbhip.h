@@ -125,6 +125,13 @@ int orb_extractor_set_input_format(OrbExtractor* h, int channels, int rgb_order)
  * ORBHIP_ERR_UNSUPPORTED.  No counterpart in the reference. */
 int orb_extractor_set_opencv_compat(OrbExtractor* h, int major, int minor);
 
+/* Where the 7x7 blur of src/ORBextractor.cc:1297-1305 is done.  fused != 0 (the default): the
+ * descriptor kernel blurs the 37 x 37 patch around each keypoint itself, in on-chip memory, and no
+ * blurred level is written; fused == 0: every level is blurred to memory first, as the reference
+ * does.  The descriptors are bit-identical either way (the same fixed-point arithmetic on the same
+ * pixels).  No counterpart in the reference. */
+int orb_extractor_set_blur_fusion(OrbExtractor* h, int fused);
+
 /* Waits for the handle's own stream, which the host-buffer entry points and the
  * accessors below use. */
 int orb_extractor_sync(OrbExtractor* h);
@@ -145,8 +152,9 @@ int orb_extractor_stage_times(OrbExtractor* h, float* ms /* ORBHIP_NUM_STAGES */
  * dst may be null to query the size only. */
 int orb_get_pyramid_level(OrbExtractor* h, int frame, int level, int padded, uint8_t* dst,
                           size_t dst_stride, int* width, int* height);
-/* The 7x7 sigma-2 blurred copy of a level that the descriptors were sampled from
- * (src/ORBextractor.cc:1297-1305). */
+/* The 7x7 sigma-2 blurred copy of a level that the descriptors are sampled from
+ * (src/ORBextractor.cc:1297-1305).  With blur fusion on, the levels of the last call's frames are
+ * blurred when this is first called after that call. */
 int orb_get_blurred_level(OrbExtractor* h, int frame, int level, uint8_t* dst, size_t dst_stride,
                           int* width, int* height);
 /* vToDistributeKeys of a level (src/ORBextractor.cc:1061-1146): FAST corners after

@@ -29,7 +29,7 @@ hipError_t launch_octree(const uint32_t*, const int*, uint32_t*, uint32_t*, int*
 void launch_blur(const uint8_t*, uint8_t*, const Plan&, const BlurItem*, int, const int*, int, hipStream_t);
 hipError_t upload_orient_tables();
 void launch_orient_desc(const uint8_t*, const uint8_t*, const uint32_t*, const int*, const Plan&, OrbKeyPoint*,
-                        uint8_t*, int*, int, int, hipStream_t);
+                        uint8_t*, int*, int, int, const int*, hipStream_t);
 void launch_pyr_resize_tile(uint8_t*, const Plan&, int, const uint32_t*, const YTab*, const int2*, int, const int2*, int,
                             int, int, int, int, hipStream_t);
 int pyr_tile_cols();
@@ -185,6 +185,9 @@ struct OrbExtractor {
   std::vector<BlurItem> blur_items;
   // device buffers
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+  // fused_blur: the descriptor kernel blurs each keypoint's patch itself and d_blur is only filled
+  // when orb_get_blurred_level asks for it (blur_stale: not yet, for the last call's frames)
+  bool fused_blur = true, blur_stale = false;
   XTab* d_xtab = nullptr;
   YTab* d_ytab = nullptr;
   FastItem* d_fast_items = nullptr;
@@ -215,7 +218,7 @@ struct OrbExtractor {
   // nothing the graph refers to (sizes, buffers, tables) has changed.
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
-    int n_frames = 0, rows = 0, cols = 0, max_kp = 0, channels = 0, rgb = 0;
+    int n_frames = 0, rows = 0, cols = 0, max_kp = 0, channels = 0, rgb = 0, fused = 0;
     int taps[4] = {0, 0, 0, 0}, gray[4] = {0, 0, 0, 0};
     const void *d_img = nullptr, *h_img = nullptr, *h_out = nullptr, *d_kps = nullptr, *d_pyr = nullptr;
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
@@ -570,9 +573,11 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));
   ORB_HIP_CHECK(launch_octree(b_cand, b_cand_cnt, b_pnode, b_sel, b_sel_cnt, P, h->ot_slots, nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[3], st));
-  launch_blur(b_pyr, b_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
+  if (!h->fused_blur) launch_blur(b_pyr, b_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[4], st));
-  launch_orient_desc(b_pyr, b_blur, b_sel, b_sel_cnt, P, d_kps, d_desc, d_nout, max_kp, nframes, st);
+  launch_orient_desc(b_pyr, b_blur, b_sel, b_sel_cnt, P, d_kps, d_desc, d_nout, max_kp, nframes,
+                     h->fused_blur ? h->taps : nullptr, st);
+  h->blur_stale = h->fused_blur;
   if (prof) { ORB_HIP_CHECK(hipEventRecord(ev[5], st)); h->prof_calls++; }
   ORB_HIP_CHECK(hipGetLastError());
   h->last_frames = frame0 + nframes;
@@ -752,6 +757,12 @@ int orb_extractor_set_opencv_compat(OrbExtractor* h, int major, int minor) {
     return ORBHIP_ERR_UNSUPPORTED;
   }
   set_opencv_tables(h, major, minor);
+  return ORBHIP_OK;
+}
+
+int orb_extractor_set_blur_fusion(OrbExtractor* h, int fused) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  h->fused_blur = fused != 0;
   return ORBHIP_OK;
 }
 
@@ -969,7 +980,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   if (small && !h->profiling) {
     OrbExtractor::GraphKey key;
     key.n_frames = n_frames; key.rows = rows; key.cols = cols; key.max_kp = max_kp; key.channels = h->channels;
-    key.rgb = h->rgb_order;
+    key.rgb = h->rgb_order; key.fused = h->fused_blur;
     for (int i = 0; i < 4; i++) { key.taps[i] = h->taps[i]; key.gray[i] = h->gray[i]; }
     key.d_img = h->d_img; key.h_img = h->h_img; key.h_out = h->h_out; key.d_kps = h->d_kps; key.d_pyr = h->d_pyr;
     if (!h->graph_exec || !(key == h->graph_key)) {
@@ -1046,6 +1057,16 @@ int orb_get_pyramid_level(OrbExtractor* h, int frame, int level, int padded, uin
 
 int orb_get_blurred_level(OrbExtractor* h, int frame, int level, uint8_t* dst, size_t dst_stride, int* width,
                           int* height) {
+  if (h && h->have_plan && h->blur_stale && h->last_frames > 0) {
+    // the last call blurred patches only: blur the levels of its frames now
+    DeviceGuard g(h->device);
+    ORB_HIP_CHECK(hipDeviceSynchronize());
+    launch_blur(h->d_pyr, h->d_blur, h->plan, h->d_blur_items, (int)h->blur_items.size(), h->taps, h->last_frames,
+                h->stream);
+    ORB_HIP_CHECK(hipGetLastError());
+    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->blur_stale = false;
+  }
   return copy_level(h, h ? h->d_blur : nullptr, frame, level, 0, dst, dst_stride, width, height);
 }
 

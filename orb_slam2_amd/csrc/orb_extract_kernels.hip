@@ -1420,6 +1420,12 @@ constexpr int D_KPW = 4;        // keypoints per wavefront (batches)
 constexpr int D_KPW_SMALL = 1;  // ... when a launch holds only a few frames: more, shorter wavefronts
 constexpr int D_RAW_ROWS = 32, D_BLR_ROWS = 48, D_PITCH = 64;  // staged rows (16 per load instruction), bytes per row
 constexpr int D_PAD = 16;                 // bytes in front of the level patch: its row 0 is read from offset -1
+// Fused form (the blurred patch is made in LDS from the level, no blurred level in memory):
+constexpr int DF_RAW_ROWS = 48, DF_PITCH = 80;     // staged level rows -21..26 around the keypoint, bytes per row (64 used)
+constexpr int DF_HP_PAIRS = 23, DF_HP_PITCH = 44;  // row pass of pairs of staged rows: dwords per pair (40 used)
+constexpr int DF_B_PITCH = 40;                     // bytes per row of the blurred patch (rows and columns -18..18 used)
+constexpr int DF_WAVE_BYTES = D_PAD + DF_RAW_ROWS * DF_PITCH + DF_HP_PAIRS * DF_HP_PITCH * 4;
+constexpr int D_WAVE_BYTES = D_PAD + (D_RAW_ROWS + D_BLR_ROWS) * D_PITCH;
 
 // Steering tables, filled by upload_orient_tables():
 //  d_patf[pair]      = (x0, x1, y0, y1) of the rBRIEF pair as floats;
@@ -1474,7 +1480,31 @@ __device__ __forceinline__ Staged od_issue(const uint8_t* __restrict__ pyr, cons
   return s;
 }
 
-template <int KPW>
+// the fused form's three pieces: rows rs, rs + 16, rs + 32 of the level patch (b0, b1 unused)
+__device__ __forceinline__ Staged od_issue_fused(const uint8_t* __restrict__ pyr, size_t lvl, int cx, int pitch, int rs,
+                                                 int seg) {
+  const int al = (cx + kXOff - 21) & 15;
+  // a base that is the same for all lanes plus a 32-bit offset of the lane
+  const uint8_t* g = pyr + lvl - 21 - al - (ptrdiff_t)21 * pitch;
+  const uint32_t off = __umul24(rs, pitch) + 16 * seg, step = 16u * (uint32_t)pitch;
+  Staged s;
+  s.a0 = *reinterpret_cast<const uint4*>(g + off);
+  s.a1 = *reinterpret_cast<const uint4*>(g + (off + step));
+  s.b0 = *reinterpret_cast<const uint4*>(g + (off + 2 * step));
+  return s;
+}
+
+// orders a wavefront's LDS stores before the loads of its other lanes that follow
+__device__ __forceinline__ void od_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// MODE 0: the descriptor samples the blurred level that blur_kernel wrote.
+// MODE 1 / 2: the blurred patch is made here, in LDS, from the level's pixels (2: taps that sum
+// to 257, saturated results) - the same fixed-point arithmetic as blur_kernel, whose row and
+// column passes are exact, so only the final rounding matters and it is the same.
+template <int KPW, int MODE>
 __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* __restrict__ pyr,
                                                                 const uint8_t* __restrict__ blur,
                                                                 const uint32_t* __restrict__ sel_all,
@@ -1482,8 +1512,9 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
                                                                 OrbKeyPoint* __restrict__ out_kps,
                                                                 uint8_t* __restrict__ out_desc,
                                                                 int* __restrict__ n_out, int max_kp, int nframes,
-                                                                int nchunks) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[D_THREADS / 64][D_PAD + (D_RAW_ROWS + D_BLR_ROWS) * D_PITCH];
+                                                                int nchunks, int t0, int t1, int t2, int t3) {
+  constexpr bool FUSED = MODE != 0;
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[D_THREADS / 64][FUSED ? DF_WAVE_BYTES : D_WAVE_BYTES];
   // Workgroups are handed to the 8 XCDs round-robin by linear index.  Give every XCD whole
   // frames, one after the other, so that the patches its wavefronts gather stay in its L2.
   const int w = blockIdx.x;
@@ -1507,7 +1538,39 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   const uint4 wm = *reinterpret_cast<const uint4*>(&d_odw[row][half][0]);
   const uint4 w1 = *reinterpret_cast<const uint4*>(&d_odw[row][half][4]);
   uint8_t* s_raw = s_patch[threadIdx.x >> 6] + D_PAD;
-  uint8_t* s_blr = s_raw + D_RAW_ROWS * D_PITCH;
+  uint8_t* s_blr = s_raw + D_RAW_ROWS * D_PITCH;                                        // MODE 0
+  uint8_t* s_hp = s_raw + DF_RAW_ROWS * DF_PITCH;                                       // fused: row-pass results
+  // fused form, row pass: item = (pair of staged rows 0..21, group of 4 columns 0..9), 220 items in
+  // 4 rounds of 64 lanes; column pass: lane = (group of 4 columns 0..9, strip 0..5 of the 7 rows
+  // from row 6 * strip on: a strip starts on an even row, its last row is the next one's first)
+  int h_src[4], h_dst[4], v_src = 0, v_dst = 0;
+  uint32_t HA0 = 0, HB0 = 0, HA1 = 0, HB1 = 0, HC1 = 0, HA2 = 0, HB2 = 0, HC2 = 0, HC3 = 0;
+  uint32_t T1 = 0, TPe0 = 0, TPe1 = 0, TPe2 = 0, TPe3 = 0, TPo0 = 0, TPo1 = 0, TPo2 = 0, TPo3 = 0;
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int rd = 0; rd < 4; rd++) {
+      const int item = lane + 64 * rd, pr = (item * 6554) >> 16, g = item - 10 * pr;  // item / 10 for item < 256
+      h_src[rd] = 2 * pr * DF_PITCH + 4 * (g - 1);
+      h_dst[rd] = pr * (DF_HP_PITCH * 4) + 16 * g;
+    }
+    const int vs = (lane * 6554) >> 16, vq = lane - 10 * vs;
+    v_src = 3 * vs * (DF_HP_PITCH * 4) + 16 * vq;
+    v_dst = 6 * vs * DF_B_PITCH + 4 * vq;
+    // Row pass: pixel j of a group of 4 uses bytes j + 1 .. j + 7 of three dwords; instead of
+    // shifting the bytes into place, each pixel has its own copies of the taps (t0 t1 t2 t3 t2 t1
+    // t0), shifted: HA* go with the first dword, HB* / T1 with the second, HC* with the third.
+    auto pack4 = [](int b0, int b1, int b2, int b3) {
+      return (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
+    };
+    HA0 = pack4(0, t0, t1, t2); HB0 = pack4(t3, t2, t1, t0);
+    HA1 = pack4(0, 0, t0, t1);  HB1 = pack4(t2, t3, t2, t1); HC1 = pack4(t0, 0, 0, 0);
+    HA2 = pack4(0, 0, 0, t0);   HB2 = pack4(t1, t2, t3, t2); HC2 = pack4(t1, t0, 0, 0);
+    T1 = pack4(t0, t1, t2, t3); HC3 = pack4(t2, t1, t0, 0);
+    TPe0 = (uint32_t)t0 | ((uint32_t)t1 << 16); TPe1 = (uint32_t)t2 | ((uint32_t)t3 << 16);
+    TPe2 = (uint32_t)t2 | ((uint32_t)t1 << 16); TPe3 = (uint32_t)t0;
+    TPo0 = (uint32_t)t0 << 16; TPo1 = (uint32_t)t1 | ((uint32_t)t2 << 16);
+    TPo2 = (uint32_t)t3 | ((uint32_t)t2 << 16); TPo3 = (uint32_t)t1 | ((uint32_t)t0 << 16);
+  }
 
   // where slot k0 + kk lives: level, output row, centre; ok = false for empty slots
   struct Loc { bool ok; int l, o, cx, cy, pitch; uint32_t v; size_t lvl; };
@@ -1542,32 +1605,42 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   const int rs = lane >> 2, seg = lane & 3;
   Staged st;
   Loc cur = locate(0);
-  if (cur.ok) st = od_issue(pyr, blur, cur.lvl, cur.cx, cur.pitch, rs, seg);
+  auto issue = [&](const Loc& q) {
+    if constexpr (FUSED) return od_issue_fused(pyr, q.lvl, q.cx, q.pitch, rs, seg);
+    else return od_issue(pyr, blur, q.lvl, q.cx, q.pitch, rs, seg);
+  };
+  if (cur.ok) st = issue(cur);
+#pragma unroll
   for (int kk = 0; kk < KPW; kk++) {
   const Loc nxt = locate(kk + 1);
   if (!cur.ok) {
-    if (nxt.ok) st = od_issue(pyr, blur, nxt.lvl, nxt.cx, nxt.pitch, rs, seg);
+    if (nxt.ok) st = issue(nxt);
     cur = nxt;
     continue;
   }
   const uint32_t v = cur.v;
   const int l = cur.l, o = cur.o, cx = cur.cx, cy = cur.cy;
   const LevelGeom& L = P.lv[l];
-  const int al = (cx + kXOff - 15) & 15, al2 = (cx + kXOff - 18) & 15;
-  {
+  const int al = (cx + kXOff - (FUSED ? 21 : 15)) & 15, al2 = (cx + kXOff - 18) & 15;
+  if constexpr (FUSED) {
+    uint4* dr = reinterpret_cast<uint4*>(&s_raw[rs * DF_PITCH + 16 * seg]);
+    dr[0] = st.a0; dr[16 * (DF_PITCH / 16)] = st.a1; dr[32 * (DF_PITCH / 16)] = st.b0;
+  } else {
     uint4* dr = reinterpret_cast<uint4*>(&s_raw[rs * D_PITCH + 16 * seg]);
     uint4* db = reinterpret_cast<uint4*>(&s_blr[rs * D_PITCH + 16 * seg]);
     dr[0] = st.a0; dr[16 * (D_PITCH / 16)] = st.a1;
     db[0] = st.b0; db[16 * (D_PITCH / 16)] = st.b1; db[32 * (D_PITCH / 16)] = st.b2;
   }
-  if (nxt.ok) st = od_issue(pyr, blur, nxt.lvl, nxt.cx, nxt.pitch, rs, seg);
-  __builtin_amdgcn_wave_barrier();
+  if (nxt.ok) st = issue(nxt);
+  od_wave_sync();
 
   // intensity centroid: lane = 2*row + half sums 16 bytes of its row (u = -16..-1 or 0..15)
   // with the weight table; m10 = sum u*I, m01 = v * sum I over the disc
   int m10, m01;
   {
-    const int sb = row * D_PITCH + al - 1 + 16 * half;  // byte offset of the lane's first pixel (-1 at most)
+    // byte offset of the lane's first pixel, u = -16 or 0 (MODE 0: -1 at most, hence the pad;
+    // fused: staged row 6 is the disc's first row, staged byte al + 21 its centre column)
+    const int sb = FUSED ? (row + 6) * DF_PITCH + al + 5 + 16 * half : row * D_PITCH + al - 1 + 16 * half;
     const uint32_t* q = reinterpret_cast<const uint32_t*>(s_raw + (sb & ~3));
     const uint32_t x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3], x4 = q[4];
     const uint32_t sh = (uint32_t)sb & 3u;
@@ -1604,7 +1677,72 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   sincos_small((double)rad, sn, cs);
   const float a = (float)cs, b = (float)sn;
   const od_f2 a2 = {a, a}, b2 = {b, b};
-  const uint8_t* ctr = &s_blr[18 * D_PITCH + 18 + al2];
+  if constexpr (FUSED) {
+    // Row pass: the group G0 + g holds the outputs at staged bytes 4 (G0 + g) .. + 3; the patch's
+    // first column (-18) is staged byte al + 3.  Pixel j of a group uses bytes j + 1 .. j + 7 of
+    // the three dwords from the one before the group on; the results of two rows share a dword.
+    const int G0 = (al + 3) >> 2;
+    uint32_t wr[4][2][3];  // every round's dwords are read before the first results are stored
+#pragma unroll
+    for (int rd = 0; rd < 4; rd++) {
+      // (the last round's idle lanes read what item 219 reads)
+      const uint8_t* src = s_raw + (rd < 3 || lane < 220 - 192 ? h_src[rd] : 2 * 21 * DF_PITCH + 4 * 8) + 4 * G0;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(src + k * DF_PITCH);
+        wr[rd][k][0] = w[0]; wr[rd][k][1] = w[1]; wr[rd][k][2] = w[2];
+      }
+    }
+#pragma unroll
+    for (int rd = 0; rd < 4; rd++) {
+      if (rd < 3 || lane < 220 - 192) {
+        uint32_t hh[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const uint32_t w0 = wr[rd][k][0], w1 = wr[rd][k][1], w2 = wr[rd][k][2];
+          // (the taps are shifted instead of the pixels)
+          hh[k][0] = __builtin_amdgcn_udot4(w1, HB0, __builtin_amdgcn_udot4(w0, HA0, 0u, false), false);
+          hh[k][1] = __builtin_amdgcn_udot4(w2, HC1, __builtin_amdgcn_udot4(w1, HB1, __builtin_amdgcn_udot4(w0, HA1, 0u, false), false), false);
+          hh[k][2] = __builtin_amdgcn_udot4(w2, HC2, __builtin_amdgcn_udot4(w1, HB2, __builtin_amdgcn_udot4(w0, HA2, 0u, false), false), false);
+          hh[k][3] = __builtin_amdgcn_udot4(w2, HC3, __builtin_amdgcn_udot4(w1, T1, 0u, false), false);
+        }
+        uint4 o;
+        // (results are below 2^16: the low halves of the two rows' sums make the dword)
+        o.x = __builtin_amdgcn_perm(hh[1][0], hh[0][0], 0x05040100u); o.y = __builtin_amdgcn_perm(hh[1][1], hh[0][1], 0x05040100u);
+        o.z = __builtin_amdgcn_perm(hh[1][2], hh[0][2], 0x05040100u); o.w = __builtin_amdgcn_perm(hh[1][3], hh[0][3], 0x05040100u);
+        *reinterpret_cast<uint4*>(s_hp + h_dst[rd]) = o;
+      }
+    }
+    od_wave_sync();
+    // Column pass: 7 output rows x 4 columns per lane from 7 pairs of rows; output row i (patch
+    // row i - 18) uses staged rows i .. i + 6.  The blurred patch overwrites the staged level.
+    if (lane < 60) {
+      const uint4* hp = reinterpret_cast<const uint4*>(s_hp + v_src);
+      uint4 v[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) v[k] = hp[k * (DF_HP_PITCH / 4)];
+#pragma unroll
+      for (int j = 0; j < 7; j++) {
+        const int p = j >> 1;
+        const uint32_t tp0 = (j & 1) ? TPo0 : TPe0, tp1 = (j & 1) ? TPo1 : TPe1, tp2 = (j & 1) ? TPo2 : TPe2, tp3 = (j & 1) ? TPo3 : TPe3;
+        uint32_t c0 = blur_dot2(v[p + 3].x, tp3, blur_dot2(v[p + 2].x, tp2, blur_dot2(v[p + 1].x, tp1, blur_dot2(v[p].x, tp0, 32768u))));
+        uint32_t c1 = blur_dot2(v[p + 3].y, tp3, blur_dot2(v[p + 2].y, tp2, blur_dot2(v[p + 1].y, tp1, blur_dot2(v[p].y, tp0, 32768u))));
+        uint32_t c2 = blur_dot2(v[p + 3].z, tp3, blur_dot2(v[p + 2].z, tp2, blur_dot2(v[p + 1].z, tp1, blur_dot2(v[p].z, tp0, 32768u))));
+        uint32_t c3 = blur_dot2(v[p + 3].w, tp3, blur_dot2(v[p + 2].w, tp2, blur_dot2(v[p + 1].w, tp1, blur_dot2(v[p].w, tp0, 32768u))));
+        if (MODE == 2) { c0 = min(c0, 0xFFFFFFu); c1 = min(c1, 0xFFFFFFu); c2 = min(c2, 0xFFFFFFu); c3 = min(c3, 0xFFFFFFu); }
+        // byte 2 of every sum is the pixel
+        const uint32_t lo = __builtin_amdgcn_perm(c1, c0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(c3, c2, 0x06020c0cu);
+        *reinterpret_cast<uint32_t*>(s_raw + v_dst + j * DF_B_PITCH) = lo | hi;
+      }
+    }
+    od_wave_sync();
+  }
+  constexpr int CP = FUSED ? DF_B_PITCH : D_PITCH;
+  // LDS address of the blurred patch's centre, less what the rounding trick below leaves in the sums
+  typedef __attribute__((address_space(3))) const uint8_t* lds_bytes;
+  const uint32_t ctr = (uint32_t)(uintptr_t)(FUSED ? (lds_bytes)&s_raw[18 * DF_B_PITCH + 18 + ((al + 3) & 3)]
+                                                   : (lds_bytes)&s_blr[18 * D_PITCH + 18 + al2]) -
+                       (0x400000u * CP + 0x4B400000u);
   int t0[4], t1[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -1612,14 +1750,15 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     const od_f2 r = X * b2 + Y * a2;  // row offsets of the two points
     const od_f2 q = X * a2 - Y * b2;  // column offsets
     // cvRound by the float adder: x + 1.5 * 2^23 rounds x to the nearest integer, ties to even,
-    // and leaves it in the low mantissa bits (|x| < 2^22) - one packed add for two points
-    // instead of a rounding and a conversion for each
+    // and leaves 0x4B400000 + x in the bits (|x| < 2^22) - one packed add for two points instead
+    // of a rounding and a conversion for each.  The low 24 bits of that, 0x400000 + x, go into a
+    // 24-bit multiply-add as they are; the constants are taken off the base address.
     const od_f2 magic = {12582912.f, 12582912.f};
     const od_f2 rm = r + magic, qm = q + magic;
-    const int r0 = __float_as_int(rm.x) - 0x4B400000, r1 = __float_as_int(rm.y) - 0x4B400000;
-    const int q0 = __float_as_int(qm.x) - 0x4B400000, q1 = __float_as_int(qm.y) - 0x4B400000;
-    t0[j] = ctr[r0 * D_PITCH + q0];
-    t1[j] = ctr[r1 * D_PITCH + q1];
+    const uint32_t i0 = (uint32_t)(__mul24(__float_as_int(rm.x), CP) + __float_as_int(qm.x)) + ctr;
+    const uint32_t i1 = (uint32_t)(__mul24(__float_as_int(rm.y), CP) + __float_as_int(qm.y)) + ctr;
+    t0[j] = *(lds_bytes)(uintptr_t)i0;
+    t1[j] = *(lds_bytes)(uintptr_t)i1;
   }
   unsigned long long bits[4];
 #pragma unroll
@@ -1824,18 +1963,27 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurIte
     hipLaunchKernelGGL(blur_kernel<false>, dim3(fchunk, nitems, nchunks), dim3(B_THREADS), 0, st, pyr, blur, P, items,
                        nitems, fchunk, nframes, taps[0], taps[1], taps[2], taps[3]);
 }
+// taps == nullptr: the descriptors sample the blurred levels in `blur`; otherwise `blur` is not
+// read and the kernel blurs each keypoint's patch itself with these taps
 void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel, const int* sel_cnt, const Plan& P,
-                        OrbKeyPoint* kps, uint8_t* desc, int* n_out, int max_kp, int nframes, hipStream_t st) {
+                        OrbKeyPoint* kps, uint8_t* desc, int* n_out, int max_kp, int nframes, const int* taps,
+                        hipStream_t st) {
   const bool small = nframes <= 8;
   const int per_wg = (D_THREADS / 64) * (small ? D_KPW_SMALL : D_KPW);
   const int nb = (P.sel_total + per_wg - 1) / per_wg;
   const int groups = (nframes + 7) / 8;  // frames are dealt to the 8 XCDs in groups
-  if (small)
-    hipLaunchKernelGGL(orient_desc_kernel<D_KPW_SMALL>, dim3((unsigned)groups * 8u * (unsigned)nb), dim3(D_THREADS), 0, st,
-                       pyr, blur, sel, sel_cnt, P, kps, desc, n_out, max_kp, nframes, nb);
-  else
-    hipLaunchKernelGGL(orient_desc_kernel<D_KPW>, dim3((unsigned)groups * 8u * (unsigned)nb), dim3(D_THREADS), 0, st, pyr,
-                       blur, sel, sel_cnt, P, kps, desc, n_out, max_kp, nframes, nb);
+  const dim3 grid((unsigned)groups * 8u * (unsigned)nb), block(D_THREADS);
+  const int mode = !taps ? 0 : taps[3] + 2 * (taps[0] + taps[1] + taps[2]) > 256 ? 2 : 1;
+  const int t0 = taps ? taps[0] : 0, t1 = taps ? taps[1] : 0, t2 = taps ? taps[2] : 0, t3 = taps ? taps[3] : 0;
+#define ORB_OD_LAUNCH(K, M)                                                                                        \
+  hipLaunchKernelGGL((orient_desc_kernel<K, M>), grid, block, 0, st, pyr, blur, sel, sel_cnt, P, kps, desc, n_out, \
+                     max_kp, nframes, nb, t0, t1, t2, t3)
+  if (small) {
+    if (mode == 0) ORB_OD_LAUNCH(D_KPW_SMALL, 0); else if (mode == 1) ORB_OD_LAUNCH(D_KPW_SMALL, 1); else ORB_OD_LAUNCH(D_KPW_SMALL, 2);
+  } else {
+    if (mode == 0) ORB_OD_LAUNCH(D_KPW, 0); else if (mode == 1) ORB_OD_LAUNCH(D_KPW, 1); else ORB_OD_LAUNCH(D_KPW, 2);
+  }
+#undef ORB_OD_LAUNCH
 }
 
 int fast_use_width() { return F_USEW; }

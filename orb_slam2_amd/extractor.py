@@ -90,6 +90,12 @@ class ORBextractor:
         reference links whichever OpenCV its build finds."""
         check(self._lib.orb_extractor_set_opencv_compat(self._h, int(major), int(minor)))
 
+    def set_blur_fusion(self, fused):
+        """True (default): the descriptor kernel blurs each keypoint's patch itself; False: the
+        levels are blurred to memory first, as the reference does (src/ORBextractor.cc:1297-1305).
+        The results are the same."""
+        check(self._lib.orb_extractor_set_blur_fusion(self._h, int(bool(fused))))
+
     def extract_batch(self, images):
         """images: (n, rows, cols) uint8 grey, or (n, rows, cols, 3|4) colour in the order
         self.mbRGB says.  Returns lists of per-frame keypoints/descriptors."""

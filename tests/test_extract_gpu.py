@@ -302,6 +302,41 @@ def test_large_batch_equals_small_batches(oracle):
         check_against(bk[f], bd[f], rk, rd)
 
 
+@pytest.mark.parametrize("compat", [(4, 5), (4, 2)])
+def test_blur_fused_into_descriptors(oracle, compat):
+    """The descriptor kernel blurs each keypoint's patch in on-chip memory by default; with the
+    levels blurred to memory first (set_blur_fusion(False), the reference's order) keypoints and
+    descriptors are bit-identical, for both tap sets (the one summing to 257 saturates), single
+    frames (one keypoint per wavefront) and batches (four), at image borders and with bright
+    patches that make the saturation matter."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd.synth import synth_sequence
+    rng = np.random.default_rng(5)
+    for rows, cols, nf, nlev in [(376, 1241, 2000, 8), (240, 320, 700, 6), (155, 411, 500, 4)]:
+        seq = synth_sequence(rows, cols, 12, seed=rows, step=2).copy()
+        seq[3:6] = np.clip(seq[3:6].astype(np.int32) * 3, 0, 255).astype(np.uint8)   # saturated regions
+        seq[6] = rng.integers(0, 256, (rows, cols), dtype=np.uint8)                  # corners everywhere, up to the border
+        seq[7] = np.where(rng.random((rows, cols)) < 0.5, 255, 250).astype(np.uint8)
+        a, b = ORBextractor(nf, 1.2, nlev, 20, 7), ORBextractor(nf, 1.2, nlev, 20, 7)
+        a.set_opencv_compat(*compat)
+        b.set_opencv_compat(*compat)
+        b.set_blur_fusion(False)
+        ak, ad = a.extract_batch(seq)
+        bk, bd = b.extract_batch(seq)
+        total = 0
+        for f in range(len(seq)):
+            assert np.array_equal(ak[f], bk[f]) and np.array_equal(ad[f], bd[f]), (rows, f)
+            total += len(ak[f])
+        assert total > 1000
+        for f in (0, 4, 6):
+            k1, d1 = a(seq[f])
+            assert np.array_equal(k1, bk[f]) and np.array_equal(d1, bd[f]), (rows, f)
+        # the blurred level is made on demand after a fused call and equals the one written up front
+        a.extract_batch(seq)
+        for l in (0, nlev - 1):
+            assert np.array_equal(a.blurred_level(l, 7), b.blurred_level(l, 7))
+
+
 def test_host_batch_in_pieces(oracle):
     """Host-buffer batches of 64 frames and more go through in pieces, each with an upload, its
     kernels and a download of its own: strided host images (rows and frames with padding), the
