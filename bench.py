@@ -40,13 +40,15 @@ def level_sizes(rows, cols, nlevels=8, f=1.2):
     return [(int(np.rint(np.float32(cols) * inv[l])), int(np.rint(np.float32(rows) * inv[l]))) for l in range(nlevels)]
 
 
-def algorithmic_bytes(rows, cols):
-    """Compulsory bytes per frame of the three bandwidth-bound stages."""
+def algorithmic_bytes(rows, cols, blur_fused=False):
+    """Compulsory bytes per frame of the three bandwidth-bound stages.  With the blur made inside the
+    descriptor kernel (no blurred level is written) there is no blur stage: its bytes, read S + write S
+    of the reference's GaussianBlur pass, are priced against that kernel's time instead."""
     sz = level_sizes(rows, cols)
     S = sum(w * h for w, h in sz)
     P = sum((w + 38) * (h + 38) for w, h in sz)
     S0, S7 = sz[0][0] * sz[0][1], sz[-1][0] * sz[-1][1]
-    return {"pyramid": (S0 + (S - S7)) + P, "fast": P, "blur": 2 * S}
+    return {"pyramid": (S0 + (S - S7)) + P, "fast": P, "orient_desc" if blur_fused else "blur": 2 * S}
 
 
 def main():
@@ -81,10 +83,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    # Rehearsal on a box with fewer GPUs than ranks: ORBHIP_BENCH_SHARE_GPU=1 puts every rank on GPU 0
+    # and the exchange on gloo (RCCL refuses two ranks on one GPU); never set for a measurement.
+    share = os.environ.get("ORBHIP_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -155,7 +165,8 @@ def main():
     ev1.record()
     barrier()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    red = torch.device("cpu") if share else dev  # where the timing reductions live (gloo: host)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=red)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
@@ -220,7 +231,7 @@ def main():
             else:
                 out, acc = odist.knn2_sharded(local_search, merge, nq, dev, world)
             barrier()
-            tk = torch.tensor([time.perf_counter() - tk0], dtype=torch.float64, device=dev)
+            tk = torch.tensor([time.perf_counter() - tk0], dtype=torch.float64, device=red)
             if world > 1:
                 dist.all_reduce(tk, op=dist.ReduceOp.MAX)
             times.append(float(tk.item()))
@@ -258,7 +269,7 @@ def main():
             check(L.orb_knn2_device_algo(local, d_q.data_ptr(), nq, d_db.data_ptr(), hi - lo, lo, 0.7,
                                          r2[0].data_ptr(), r2[1].data_ptr(), r2[2].data_ptr(), None, stream, 1))
             barrier()
-            tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
+            tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=red)
             if world > 1:
                 dist.all_reduce(tp, op=dist.ReduceOp.MAX)
             tp = float(tp.item())
@@ -336,12 +347,18 @@ def main():
                 launches = {k.replace("_kernel", ""): v.get("launches_per_step", 1) for k, v in tj["kernels"].items()}
         except (OSError, ValueError, KeyError):
             pass
-        ab = algorithmic_bytes(ROWS, COLS)
         names = ["pyramid", "fast", "quadtree", "blur", "orient_desc"]
         stages = {nm: round(float(ms), 4) for nm, ms in zip(names, stage_ms)}
+        # the blur stage is empty when the descriptor kernel blurs its patches itself (the default)
+        blur_fused = stages["blur"] < 0.05 * stages["orient_desc"]
+        ab = algorithmic_bytes(ROWS, COLS, blur_fused)
+        if blur_fused:
+            stages["orient_desc"] = round(stages["orient_desc"] + stages.pop("blur"), 4)
         stages["search_by_projection"] = round(match_ms, 4)
         gbs = {k: ab[k] * B / (stages[k] * 1e-3) / 1e9 for k in ab}
-        dom = max(ab, key=lambda k: stages[k])
+        # the roofline object is for the stage that reads every pixel through one kernel and is slowest
+        # against its bytes: FAST or the pyramid (the descriptor kernel gathers patches: see stage_gbs)
+        dom = max(("pyramid", "fast"), key=lambda k: stages[k])
         out = {
             "metric": "ORB frames/s (1241x376, 2000kp, 8 lvl) + Hamming kNN-2 matches/s at 1-8 GPU",
             "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

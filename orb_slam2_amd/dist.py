@@ -23,8 +23,14 @@ def knn2_sharded(local_search, merge, n_q, device, world, group=None):
     res = local_search()
     assert res.shape == (3, n_q) and res.dtype == torch.int32
     if world > 1:
-        gathered = torch.empty((world * 3, n_q), dtype=torch.int32, device=device)
-        dist.all_gather_into_tensor(gathered, res.contiguous(), group=group)
+        if res.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo carries host tensors only: stage through the host (CPU rehearsals of the GPU path)
+            gathered = torch.empty((world * 3, n_q), dtype=torch.int32)
+            dist.all_gather_into_tensor(gathered, res.cpu().contiguous(), group=group)
+            gathered = gathered.to(device)
+        else:
+            gathered = torch.empty((world * 3, n_q), dtype=torch.int32, device=device)
+            dist.all_gather_into_tensor(gathered, res.contiguous(), group=group)
         g = gathered.view(world, 3, n_q).permute(1, 0, 2).contiguous()
     else:
         g = res.reshape(3, 1, n_q)
