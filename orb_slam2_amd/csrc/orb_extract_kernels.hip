@@ -1416,14 +1416,22 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 constexpr int D_THREADS = 256;
-constexpr int D_KPW = 4;        // keypoints per wavefront (batches)
+constexpr int D_KPW = 8;        // keypoints per wavefront (batches)
 constexpr int D_KPW_SMALL = 1;  // ... when a launch holds only a few frames: more, shorter wavefronts
 constexpr int D_RAW_ROWS = 32, D_BLR_ROWS = 48, D_PITCH = 64;  // staged rows (16 per load instruction), bytes per row
 constexpr int D_PAD = 16;                 // bytes in front of the level patch: its row 0 is read from offset -1
 // Fused form (the blurred patch is made in LDS from the level, no blurred level in memory):
-constexpr int DF_RAW_ROWS = 48, DF_PITCH = 80;     // staged level rows -21..26 around the keypoint, bytes per row (64 used)
-constexpr int DF_HP_PAIRS = 23, DF_HP_PITCH = 44;  // row pass of pairs of staged rows: dwords per pair (40 used)
-constexpr int DF_B_PITCH = 40;                     // bytes per row of the blurred patch (rows and columns -18..18 used)
+// The three pitches are chosen for the LDS banks (dword banks: 32 for 4-byte accesses and for stores,
+// 64 for 16-byte reads; lanes are served in fixed groups).  Row pass: lane = item (pair of rows pr,
+// column group g), 10 groups per pair; with 21 dwords per row a pair is 42 = 10 mod 32, so a lane's
+// bank is its item number and the 32 lanes of a group never share one (at 20 dwords every read took
+// two turns).  The price is that staged rows are only dword-aligned: they are stored as dwords, which
+// costs the same LDS time as the 16-byte stores did.  Column pass: lane = (strip vs, group vq) reads
+// 16 bytes at 3 vs pairs + 4 vq dwords; 3 * 56 = 40 mod 64 puts lane 10 vs + vq on 16-byte slot
+// (lane mod 16), distinct within each of the instruction's 16-lane groups (at 44 dwords: three turns).
+constexpr int DF_RAW_ROWS = 48, DF_PITCH = 84;     // staged level rows -21..26 around the keypoint, bytes per row (64 used)
+constexpr int DF_HP_PAIRS = 23, DF_HP_PITCH = 56;  // row pass of pairs of staged rows: dwords per pair (40 used)
+constexpr int DF_B_PITCH = 48;                     // bytes per row of the blurred patch (rows and columns -18..18 used)
 constexpr int DF_WAVE_BYTES = D_PAD + DF_RAW_ROWS * DF_PITCH + DF_HP_PAIRS * DF_HP_PITCH * 4;
 constexpr int D_WAVE_BYTES = D_PAD + (D_RAW_ROWS + D_BLR_ROWS) * D_PITCH;
 
@@ -1572,44 +1580,137 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     TPo2 = (uint32_t)t3 | ((uint32_t)t2 << 16); TPo3 = (uint32_t)t1 | ((uint32_t)t0 << 16);
   }
 
-  // where slot k0 + kk lives: level, output row, centre; ok = false for empty slots
+  // Where the wavefront's slots live.  Lane j works out slot k0 + j once: its level (the last one
+  // whose first slot is not beyond it), its row of the frame's output (the counts of the levels
+  // before it, plus its index in its own) and whether it holds a keypoint at all; the loop below
+  // takes keypoint kk's answer from lane kk.
+  uint32_t loc_v;  // level | output row << 4 | valid << 31
+  {
+    const int k = k0 + lane;
+    int l = 0, first = 0;  // first slots grow with the level: the level is the number of those not beyond k
+#pragma unroll
+    for (int j = 1; j < kMaxLevels; j++) {
+      const bool ge = j < P.nlevels && k >= P.lv[j].sel_off;
+      l += ge ? 1 : 0;
+      first = ge ? P.lv[j].sel_off : first;
+    }
+    // lane j holds level j's count (lanes from nlevels on: 0); running sums along the first 16 lanes
+    int incl = mycnt;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr 1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);  // row_shr 2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr 4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr 8
+    const int cnt_l = __builtin_amdgcn_ds_bpermute(4 * l, mycnt);
+    const int before = __builtin_amdgcn_ds_bpermute(4 * l, incl) - cnt_l;
+    if (k == 0) n_out[f] = __builtin_amdgcn_readlane(incl, 15);
+    const int i = k - first, o = before + i;
+    const bool ok = lane < KPW && k < P.sel_total && i < cnt_l && o < max_kp;
+    loc_v = (uint32_t)l | ((uint32_t)o << 4) | (ok ? 0x80000000u : 0u);
+  }
   struct Loc { bool ok; int l, o, cx, cy, pitch; uint32_t v; size_t lvl; };
   auto locate = [&](int kk) {
     Loc q;
     q.ok = false; q.l = 0; q.o = 0; q.cx = 0; q.cy = 0; q.pitch = 0; q.v = 0; q.lvl = 0;
-    const int k = k0 + kk;
-    if (kk >= KPW || k >= P.sel_total) return q;
+    if (kk >= KPW) return q;
+    const uint32_t p = __builtin_amdgcn_readlane(loc_v, kk);
+    if (!(p >> 31)) return q;
+    q.ok = true;
     q.v = __builtin_amdgcn_readlane(myv, kk);
-    int l = 0, before = 0, tot = 0, cnt_l = 0;
-#pragma unroll
-    for (int j = 0; j < kMaxLevels; j++) {
-      const int c = __builtin_amdgcn_readlane(mycnt, j);
-      tot += c;
-      if (j < P.nlevels && k >= P.lv[j].sel_off) { l = j; cnt_l = c; before = tot - c; }
-    }
-    if (k == 0 && lane == 0) n_out[f] = tot;
-    const int i = k - P.lv[l].sel_off;
-    q.l = l; q.o = before + i;
-    q.ok = i < cnt_l && q.o < max_kp;
+    q.l = (int)(p & 15u); q.o = (int)((p >> 4) & 0x7FFFFFFu);
     q.cx = (int)(q.v & kCoordMask) + kBorder; q.cy = (int)((q.v >> kCoordBits) & kCoordMask) + kBorder;
-    q.pitch = P.lv[l].pitch;
-    q.lvl = (size_t)f * P.slab + P.lv[l].off + (size_t)(q.cy + kEdge) * q.pitch + q.cx + kXOff;
+    q.pitch = P.lv[q.l].pitch;
+    q.lvl = (size_t)f * P.slab + P.lv[q.l].off + (size_t)(q.cy + kEdge) * q.pitch + q.cx + kXOff;
     return q;
   };
+  // sum over the wavefront: within rows of 16 lanes by DPP, then the four row totals
+  auto wave_sum = [](int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false);  // row_ror 4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);  // row_ror 8
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+           __builtin_amdgcn_readlane(x, 48);
+  };
+  // angle (degrees) and the rotation's cosine and sine from the patch moments
+  auto steer = [](int m01, int m10, float& angle, float& a, float& b) {
+    angle = fast_atan2_deg((float)m01, (float)m10);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float rad = __fmul_rn(angle, factorPI);
+    double sn, cs;
+    sincos_small((double)rad, sn, cs);
+    a = (float)cs; b = (float)sn;
+  };
+  // With several keypoints per wavefront the orientations are made first, for all of them: a lane
+  // takes the 16 bytes of its half row of the disc straight from the level (a dword-aligned
+  // 16-byte load and the dword after it, shifted into place), the moments of keypoint j end up in
+  // lane j, and the angle, cosine and sine - the same arithmetic in every lane, whatever it holds -
+  // are evaluated once for the wavefront's keypoints instead of once per keypoint.  The loop
+  // below then finds a keypoint's angle and rotation in lane j of these registers.
+  const int rs = lane >> 2, seg = lane & 3;
+  Staged st;
+  auto issue = [&](const Loc& q) {
+    if constexpr (FUSED) return od_issue_fused(pyr, q.lvl, q.cx, q.pitch, rs, seg);
+    else return od_issue(pyr, blur, q.lvl, q.cx, q.pitch, rs, seg);
+  };
+  Loc cur;
+  float ang_v = 0.f, cos_v = 1.f, sin_v = 0.f;
+  if constexpr (KPW > 1) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+    u32x4 c4[KPW];
+    uint32_t c1[KPW], csh[KPW];
+    bool cok[KPW];
+#pragma unroll
+    for (int kk = 0; kk < KPW; kk++) {
+      const Loc q = locate(kk);
+      cok[kk] = q.ok;
+      c4[kk] = u32x4{0u, 0u, 0u, 0u}; c1[kk] = 0u; csh[kk] = 0u;
+      if (q.ok) {
+        // first byte: column -16 (left half, weight 0) or 0 (right half) of row `row` - 15, as a
+        // dword-aligned address that is the same for all lanes plus a 32-bit offset of the lane
+        const uintptr_t g0 = reinterpret_cast<uintptr_t>(pyr + q.lvl - (ptrdiff_t)15 * q.pitch - 16);
+        const uint8_t* ga = reinterpret_cast<const uint8_t*>(g0 & ~(uintptr_t)3);
+        const uint32_t t = __umul24(row, q.pitch) + (16u * half + ((uint32_t)g0 & 3u));
+        csh[kk] = t & 3u;
+        c4[kk] = *reinterpret_cast<const u32x4*>(ga + (t & ~3u));
+        c1[kk] = *reinterpret_cast<const uint32_t*>(ga + (t & ~3u) + 16);
+      }
+      if (kk == 0) {  // the first keypoint's patches are on their way while the moments are summed
+        cur = q;
+        if (q.ok) st = issue(q);
+      }
+    }
+    int m10_v = 0, m01_v = 0;
+#pragma unroll
+    for (int kk = 0; kk < KPW; kk++) {
+      if (!cok[kk]) continue;
+      const uint32_t sh = csh[kk];
+      const uint32_t y0 = __builtin_amdgcn_alignbyte(c4[kk].y, c4[kk].x, sh), y1 = __builtin_amdgcn_alignbyte(c4[kk].z, c4[kk].y, sh);
+      const uint32_t y2 = __builtin_amdgcn_alignbyte(c4[kk].w, c4[kk].z, sh), y3 = __builtin_amdgcn_alignbyte(c1[kk], c4[kk].w, sh);
+      uint32_t su = __builtin_amdgcn_udot4(y0, wm.x, 0u, false);
+      su = __builtin_amdgcn_udot4(y1, wm.y, su, false);
+      su = __builtin_amdgcn_udot4(y2, wm.z, su, false);
+      su = __builtin_amdgcn_udot4(y3, wm.w, su, false);
+      uint32_t s1 = __builtin_amdgcn_udot4(y0, w1.x, 0u, false);
+      s1 = __builtin_amdgcn_udot4(y1, w1.y, s1, false);
+      s1 = __builtin_amdgcn_udot4(y2, w1.z, s1, false);
+      s1 = __builtin_amdgcn_udot4(y3, w1.w, s1, false);
+      const int m10 = wave_sum(half ? (int)su : -(int)su);
+      const int m01 = wave_sum((row - 15) * (int)s1);
+      if (lane == kk) m10_v = m10;
+      if (lane == kk) m01_v = m01;
+    }
+    steer(m01_v, m10_v, ang_v, cos_v, sin_v);
+  }
   // The two patches of a keypoint are staged in the wave's LDS region: rows -15..15 of the
   // level (orientation disc) and rows -18..18 of the blurred level (a rotated pattern point
   // reaches at most round(13*sqrt(2)) = 18 px), 64 bytes per row from a 16-byte aligned
   // start.  A lane moves 16 bytes, a load instruction 16 rows, so a keypoint takes five of
   // them; the rows staged beyond the patches (up to 29 below the centre) still lie in the
   // slab's frame.  The loads of the next keypoint are issued before the current one is computed.
-  const int rs = lane >> 2, seg = lane & 3;
-  Staged st;
-  Loc cur = locate(0);
-  auto issue = [&](const Loc& q) {
-    if constexpr (FUSED) return od_issue_fused(pyr, q.lvl, q.cx, q.pitch, rs, seg);
-    else return od_issue(pyr, blur, q.lvl, q.cx, q.pitch, rs, seg);
-  };
-  if (cur.ok) st = issue(cur);
+  if constexpr (KPW == 1) {
+    cur = locate(0);
+    if (cur.ok) st = issue(cur);
+  }
 #pragma unroll
   for (int kk = 0; kk < KPW; kk++) {
   const Loc nxt = locate(kk + 1);
@@ -1623,8 +1724,12 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   const LevelGeom& L = P.lv[l];
   const int al = (cx + kXOff - (FUSED ? 21 : 15)) & 15, al2 = (cx + kXOff - 18) & 15;
   if constexpr (FUSED) {
-    uint4* dr = reinterpret_cast<uint4*>(&s_raw[rs * DF_PITCH + 16 * seg]);
-    dr[0] = st.a0; dr[16 * (DF_PITCH / 16)] = st.a1; dr[32 * (DF_PITCH / 16)] = st.b0;
+    uint32_t* dr = reinterpret_cast<uint32_t*>(&s_raw[rs * DF_PITCH + 16 * seg]);
+    auto put = [&](int rows, const uint4& v) {
+      uint32_t* d = dr + rows * (DF_PITCH / 4);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    };
+    put(0, st.a0); put(16, st.a1); put(32, st.b0);
   } else {
     uint4* dr = reinterpret_cast<uint4*>(&s_raw[rs * D_PITCH + 16 * seg]);
     uint4* db = reinterpret_cast<uint4*>(&s_blr[rs * D_PITCH + 16 * seg]);
@@ -1634,48 +1739,41 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   if (nxt.ok) st = issue(nxt);
   od_wave_sync();
 
-  // intensity centroid: lane = 2*row + half sums 16 bytes of its row (u = -16..-1 or 0..15)
-  // with the weight table; m10 = sum u*I, m01 = v * sum I over the disc
-  int m10, m01;
-  {
-    // byte offset of the lane's first pixel, u = -16 or 0 (MODE 0: -1 at most, hence the pad;
-    // fused: staged row 6 is the disc's first row, staged byte al + 21 its centre column)
-    const int sb = FUSED ? (row + 6) * DF_PITCH + al + 5 + 16 * half : row * D_PITCH + al - 1 + 16 * half;
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(s_raw + (sb & ~3));
-    const uint32_t x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3], x4 = q[4];
-    const uint32_t sh = (uint32_t)sb & 3u;
-    const uint32_t y0 = __builtin_amdgcn_alignbyte(x1, x0, sh), y1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
-    const uint32_t y2 = __builtin_amdgcn_alignbyte(x3, x2, sh), y3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
-    uint32_t su = __builtin_amdgcn_udot4(y0, wm.x, 0u, false);
-    su = __builtin_amdgcn_udot4(y1, wm.y, su, false);
-    su = __builtin_amdgcn_udot4(y2, wm.z, su, false);
-    su = __builtin_amdgcn_udot4(y3, wm.w, su, false);
-    uint32_t s1 = __builtin_amdgcn_udot4(y0, w1.x, 0u, false);
-    s1 = __builtin_amdgcn_udot4(y1, w1.y, s1, false);
-    s1 = __builtin_amdgcn_udot4(y2, w1.z, s1, false);
-    s1 = __builtin_amdgcn_udot4(y3, w1.w, s1, false);
-    m10 = half ? (int)su : -(int)su;
-    m01 = (row - 15) * (int)s1;
+  float angle, a, b;
+  if constexpr (KPW == 1) {
+    // intensity centroid: lane = 2*row + half sums 16 bytes of its row (u = -16..-1 or 0..15)
+    // with the weight table; m10 = sum u*I, m01 = v * sum I over the disc
+    int m10, m01;
+    {
+      // byte offset of the lane's first pixel, u = -16 or 0 (MODE 0: -1 at most, hence the pad;
+      // fused: staged row 6 is the disc's first row, staged byte al + 21 its centre column)
+      const int sb = FUSED ? (row + 6) * DF_PITCH + al + 5 + 16 * half : row * D_PITCH + al - 1 + 16 * half;
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(s_raw + (sb & ~3));
+      const uint32_t x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3], x4 = q[4];
+      const uint32_t sh = (uint32_t)sb & 3u;
+      const uint32_t y0 = __builtin_amdgcn_alignbyte(x1, x0, sh), y1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
+      const uint32_t y2 = __builtin_amdgcn_alignbyte(x3, x2, sh), y3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
+      uint32_t su = __builtin_amdgcn_udot4(y0, wm.x, 0u, false);
+      su = __builtin_amdgcn_udot4(y1, wm.y, su, false);
+      su = __builtin_amdgcn_udot4(y2, wm.z, su, false);
+      su = __builtin_amdgcn_udot4(y3, wm.w, su, false);
+      uint32_t s1 = __builtin_amdgcn_udot4(y0, w1.x, 0u, false);
+      s1 = __builtin_amdgcn_udot4(y1, w1.y, s1, false);
+      s1 = __builtin_amdgcn_udot4(y2, w1.z, s1, false);
+      s1 = __builtin_amdgcn_udot4(y3, w1.w, s1, false);
+      m10 = half ? (int)su : -(int)su;
+      m01 = (row - 15) * (int)s1;
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    steer(m01, m10, angle, a, b);
+  } else {
+    angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_v), kk));
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cos_v), kk));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sin_v), kk));
   }
-  // sum over the wavefront: within rows of 16 lanes by DPP, then the four row totals
-  auto wave_sum = [](int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    x += __builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false);  // row_ror 4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);  // row_ror 8
-    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
-           __builtin_amdgcn_readlane(x, 48);
-  };
-  m10 = wave_sum(m10);
-  m01 = wave_sum(m01);
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
 
   // steered BRIEF on the blurred patch (two sample points per packed operation)
-  const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  const float rad = __fmul_rn(angle, factorPI);
-  double sn, cs;
-  sincos_small((double)rad, sn, cs);
-  const float a = (float)cs, b = (float)sn;
   const od_f2 a2 = {a, a}, b2 = {b, b};
   if constexpr (FUSED) {
     // Row pass: the group G0 + g holds the outputs at staged bytes 4 (G0 + g) .. + 3; the patch's
