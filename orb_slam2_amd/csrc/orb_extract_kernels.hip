@@ -1473,7 +1473,7 @@ typedef float od_f2 __attribute__((ext_vector_type(2)));
 
 // The 16-byte pieces of a keypoint's two patches that one lane moves (see the kernel).
 struct Staged { uint4 a0, a1, b0, b1, b2; };
-__device__ __forceinline__ Staged od_issue(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t lvl,
+__device__ __forceinline__ Staged od_issue(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, uint32_t lvl,
                                            int cx, int pitch, int rs, int seg) {
   const int al = (cx + kXOff - 15) & 15, al2 = (cx + kXOff - 18) & 15;
   const size_t step = (size_t)16 * pitch;
@@ -1489,11 +1489,11 @@ __device__ __forceinline__ Staged od_issue(const uint8_t* __restrict__ pyr, cons
 }
 
 // the fused form's three pieces: rows rs, rs + 16, rs + 32 of the level patch (b0, b1 unused)
-__device__ __forceinline__ Staged od_issue_fused(const uint8_t* __restrict__ pyr, size_t lvl, int cx, int pitch, int rs,
+__device__ __forceinline__ Staged od_issue_fused(const uint8_t* __restrict__ pyr, uint32_t lvl, int cx, int pitch, int rs,
                                                  int seg) {
   const int al = (cx + kXOff - 21) & 15;
   // a base that is the same for all lanes plus a 32-bit offset of the lane
-  const uint8_t* g = pyr + lvl - 21 - al - (ptrdiff_t)21 * pitch;
+  const uint8_t* g = pyr + (lvl - 21 - al - 21 * (uint32_t)pitch);
   const uint32_t off = __umul24(rs, pitch) + 16 * seg, step = 16u * (uint32_t)pitch;
   Staged s;
   s.a0 = *reinterpret_cast<const uint4*>(g + off);
@@ -1527,10 +1527,12 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   // frames, one after the other, so that the patches its wavefronts gather stay in its L2.
   const int w = blockIdx.x;
   const int xcd = w & 7, slot = w >> 3;
-  const int f = (slot / nchunks) * 8 + xcd;
+  const int f = __builtin_amdgcn_readfirstlane((slot / nchunks) * 8 + xcd);
   if (f >= nframes) return;
   const int chunk = slot - (slot / nchunks) * nchunks;
   const int lane = threadIdx.x & 63;
+  const uint8_t* const fpyr = pyr + (size_t)f * P.slab;   // the frame's slab
+  const uint8_t* const fblur = blur + (size_t)f * P.slab;
   // A wavefront takes KPW consecutive slots of the per-frame selected array, so that the
   // steering tables (constant per lane) are fetched once for all of them.
   const int k0 = __builtin_amdgcn_readfirstlane((chunk * (D_THREADS / 64) + (int)(threadIdx.x >> 6)) * KPW);
@@ -1584,16 +1586,19 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   // whose first slot is not beyond it), its row of the frame's output (the counts of the levels
   // before it, plus its index in its own) and whether it holds a keypoint at all; the loop below
   // takes keypoint kk's answer from lane kk.
-  uint32_t loc_v;  // level | output row << 4 | valid << 31
+  uint32_t loc_v;   // level | output row << 4 | valid << 31
+  uint32_t lvl_v;   // offset of the keypoint's pixel in the frame's slab
+  int pitch_v;      // row pitch of its level
+  float scale_v, size_v;  // mvScaleFactor of its level, keypoint size
   {
+    // lane j: level j's entries of the plan; a keypoint's lane takes those of its level with a lane permute
+    const LevelGeom& G = P.lv[min(lane, kMaxLevels - 1)];
+    const int t_first = G.sel_off, t_pitch = G.pitch, t_off = G.off;
+    const float t_scale = G.scale, t_size = G.kp_size;
     const int k = k0 + lane;
-    int l = 0, first = 0;  // first slots grow with the level: the level is the number of those not beyond k
+    int l = 0;  // first slots grow with the level: the level is the number of those not beyond k
 #pragma unroll
-    for (int j = 1; j < kMaxLevels; j++) {
-      const bool ge = j < P.nlevels && k >= P.lv[j].sel_off;
-      l += ge ? 1 : 0;
-      first = ge ? P.lv[j].sel_off : first;
-    }
+    for (int j = 1; j < kMaxLevels; j++) l += (j < P.nlevels && k >= P.lv[j].sel_off) ? 1 : 0;
     // lane j holds level j's count (lanes from nlevels on: 0); running sums along the first 16 lanes
     int incl = mycnt;
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr 1
@@ -1602,12 +1607,20 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr 8
     const int cnt_l = __builtin_amdgcn_ds_bpermute(4 * l, mycnt);
     const int before = __builtin_amdgcn_ds_bpermute(4 * l, incl) - cnt_l;
+    const int first = __builtin_amdgcn_ds_bpermute(4 * l, t_first);
+    const int pitch = __builtin_amdgcn_ds_bpermute(4 * l, t_pitch);
+    const int off = __builtin_amdgcn_ds_bpermute(4 * l, t_off);
+    scale_v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * l, __builtin_bit_cast(int, t_scale)));
+    size_v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * l, __builtin_bit_cast(int, t_size)));
     if (k == 0) n_out[f] = __builtin_amdgcn_readlane(incl, 15);
     const int i = k - first, o = before + i;
     const bool ok = lane < KPW && k < P.sel_total && i < cnt_l && o < max_kp;
     loc_v = (uint32_t)l | ((uint32_t)o << 4) | (ok ? 0x80000000u : 0u);
+    const int cx = (int)(myv & kCoordMask) + kBorder, cy = (int)((myv >> kCoordBits) & kCoordMask) + kBorder;
+    pitch_v = pitch;
+    lvl_v = (uint32_t)off + (uint32_t)(cy + kEdge) * (uint32_t)pitch + (uint32_t)(cx + kXOff);
   }
-  struct Loc { bool ok; int l, o, cx, cy, pitch; uint32_t v; size_t lvl; };
+  struct Loc { bool ok; int l, o, cx, cy, pitch; uint32_t v; uint32_t lvl; };
   auto locate = [&](int kk) {
     Loc q;
     q.ok = false; q.l = 0; q.o = 0; q.cx = 0; q.cy = 0; q.pitch = 0; q.v = 0; q.lvl = 0;
@@ -1618,8 +1631,8 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     q.v = __builtin_amdgcn_readlane(myv, kk);
     q.l = (int)(p & 15u); q.o = (int)((p >> 4) & 0x7FFFFFFu);
     q.cx = (int)(q.v & kCoordMask) + kBorder; q.cy = (int)((q.v >> kCoordBits) & kCoordMask) + kBorder;
-    q.pitch = P.lv[q.l].pitch;
-    q.lvl = (size_t)f * P.slab + P.lv[q.l].off + (size_t)(q.cy + kEdge) * q.pitch + q.cx + kXOff;
+    q.pitch = __builtin_amdgcn_readlane(pitch_v, kk);
+    q.lvl = __builtin_amdgcn_readlane(lvl_v, kk);
     return q;
   };
   // sum over the wavefront: within rows of 16 lanes by DPP, then the four row totals
@@ -1649,12 +1662,12 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   const int rs = lane >> 2, seg = lane & 3;
   Staged st;
   auto issue = [&](const Loc& q) {
-    if constexpr (FUSED) return od_issue_fused(pyr, q.lvl, q.cx, q.pitch, rs, seg);
-    else return od_issue(pyr, blur, q.lvl, q.cx, q.pitch, rs, seg);
+    if constexpr (FUSED) return od_issue_fused(fpyr, q.lvl, q.cx, q.pitch, rs, seg);
+    else return od_issue(fpyr, fblur, q.lvl, q.cx, q.pitch, rs, seg);
   };
   Loc cur;
   float ang_v = 0.f, cos_v = 1.f, sin_v = 0.f;
-  if constexpr (KPW > 1) {
+  {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
     u32x4 c4[KPW];
     uint32_t c1[KPW], csh[KPW];
@@ -1667,7 +1680,7 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
       if (q.ok) {
         // first byte: column -16 (left half, weight 0) or 0 (right half) of row `row` - 15, as a
         // dword-aligned address that is the same for all lanes plus a 32-bit offset of the lane
-        const uintptr_t g0 = reinterpret_cast<uintptr_t>(pyr + q.lvl - (ptrdiff_t)15 * q.pitch - 16);
+        const uintptr_t g0 = reinterpret_cast<uintptr_t>(fpyr + (q.lvl - 15u * (uint32_t)q.pitch - 16u));
         const uint8_t* ga = reinterpret_cast<const uint8_t*>(g0 & ~(uintptr_t)3);
         const uint32_t t = __umul24(row, q.pitch) + (16u * half + ((uint32_t)g0 & 3u));
         csh[kk] = t & 3u;
@@ -1700,6 +1713,19 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
       if (lane == kk) m01_v = m01;
     }
     steer(m01_v, m10_v, ang_v, cos_v, sin_v);
+    // the keypoint records (epilogue of operator(): level coordinates scaled to the image), lane j's own
+    if (loc_v >> 31) {
+      const int l = (int)(loc_v & 15u), o = (int)((loc_v >> 4) & 0x7FFFFFFu);
+      const int cx = (int)(myv & kCoordMask) + kBorder, cy = (int)((myv >> kCoordBits) & kCoordMask) + kBorder;
+      OrbKeyPoint kp;
+      kp.x = l ? __fmul_rn((float)cx, scale_v) : (float)cx;
+      kp.y = l ? __fmul_rn((float)cy, scale_v) : (float)cy;
+      kp.size = size_v;
+      kp.angle = ang_v;
+      kp.response = (float)(myv >> 24);
+      kp.octave = l;
+      out_kps[(size_t)f * max_kp + o] = kp;
+    }
   }
   // The two patches of a keypoint are staged in the wave's LDS region: rows -15..15 of the
   // level (orientation disc) and rows -18..18 of the blurred level (a rotated pattern point
@@ -1707,10 +1733,6 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   // start.  A lane moves 16 bytes, a load instruction 16 rows, so a keypoint takes five of
   // them; the rows staged beyond the patches (up to 29 below the centre) still lie in the
   // slab's frame.  The loads of the next keypoint are issued before the current one is computed.
-  if constexpr (KPW == 1) {
-    cur = locate(0);
-    if (cur.ok) st = issue(cur);
-  }
 #pragma unroll
   for (int kk = 0; kk < KPW; kk++) {
   const Loc nxt = locate(kk + 1);
@@ -1719,9 +1741,7 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     cur = nxt;
     continue;
   }
-  const uint32_t v = cur.v;
-  const int l = cur.l, o = cur.o, cx = cur.cx, cy = cur.cy;
-  const LevelGeom& L = P.lv[l];
+  const int o = cur.o, cx = cur.cx;
   const int al = (cx + kXOff - (FUSED ? 21 : 15)) & 15, al2 = (cx + kXOff - 18) & 15;
   if constexpr (FUSED) {
     uint32_t* dr = reinterpret_cast<uint32_t*>(&s_raw[rs * DF_PITCH + 16 * seg]);
@@ -1739,39 +1759,8 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   if (nxt.ok) st = issue(nxt);
   od_wave_sync();
 
-  float angle, a, b;
-  if constexpr (KPW == 1) {
-    // intensity centroid: lane = 2*row + half sums 16 bytes of its row (u = -16..-1 or 0..15)
-    // with the weight table; m10 = sum u*I, m01 = v * sum I over the disc
-    int m10, m01;
-    {
-      // byte offset of the lane's first pixel, u = -16 or 0 (MODE 0: -1 at most, hence the pad;
-      // fused: staged row 6 is the disc's first row, staged byte al + 21 its centre column)
-      const int sb = FUSED ? (row + 6) * DF_PITCH + al + 5 + 16 * half : row * D_PITCH + al - 1 + 16 * half;
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(s_raw + (sb & ~3));
-      const uint32_t x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3], x4 = q[4];
-      const uint32_t sh = (uint32_t)sb & 3u;
-      const uint32_t y0 = __builtin_amdgcn_alignbyte(x1, x0, sh), y1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
-      const uint32_t y2 = __builtin_amdgcn_alignbyte(x3, x2, sh), y3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
-      uint32_t su = __builtin_amdgcn_udot4(y0, wm.x, 0u, false);
-      su = __builtin_amdgcn_udot4(y1, wm.y, su, false);
-      su = __builtin_amdgcn_udot4(y2, wm.z, su, false);
-      su = __builtin_amdgcn_udot4(y3, wm.w, su, false);
-      uint32_t s1 = __builtin_amdgcn_udot4(y0, w1.x, 0u, false);
-      s1 = __builtin_amdgcn_udot4(y1, w1.y, s1, false);
-      s1 = __builtin_amdgcn_udot4(y2, w1.z, s1, false);
-      s1 = __builtin_amdgcn_udot4(y3, w1.w, s1, false);
-      m10 = half ? (int)su : -(int)su;
-      m01 = (row - 15) * (int)s1;
-    }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    steer(m01, m10, angle, a, b);
-  } else {
-    angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_v), kk));
-    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cos_v), kk));
-    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sin_v), kk));
-  }
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cos_v), kk));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sin_v), kk));
 
   // steered BRIEF on the blurred patch (two sample points per packed operation)
   const od_f2 a2 = {a, a}, b2 = {b, b};
@@ -1864,16 +1853,6 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
   if (lane < 4) {
     const unsigned long long w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
     reinterpret_cast<unsigned long long*>(out_desc + ((size_t)f * max_kp + o) * 32)[lane] = w;
-  }
-  if (lane == 0) {
-    OrbKeyPoint kp;
-    kp.x = l ? __fmul_rn((float)cx, L.scale) : (float)cx;
-    kp.y = l ? __fmul_rn((float)cy, L.scale) : (float)cy;
-    kp.size = L.kp_size;
-    kp.angle = angle;
-    kp.response = (float)(v >> 24);
-    kp.octave = l;
-    out_kps[(size_t)f * max_kp + o] = kp;
   }
   cur = nxt;
   }  // keypoints of this wavefront
