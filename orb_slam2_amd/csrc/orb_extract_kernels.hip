@@ -1671,31 +1671,28 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
     u32x4 c4[KPW];
     uint32_t c1[KPW], csh[KPW];
-    bool cok[KPW];
 #pragma unroll
     for (int kk = 0; kk < KPW; kk++) {
       const Loc q = locate(kk);
-      cok[kk] = q.ok;
-      c4[kk] = u32x4{0u, 0u, 0u, 0u}; c1[kk] = 0u; csh[kk] = 0u;
-      if (q.ok) {
-        // first byte: column -16 (left half, weight 0) or 0 (right half) of row `row` - 15, as a
-        // dword-aligned address that is the same for all lanes plus a 32-bit offset of the lane
-        const uintptr_t g0 = reinterpret_cast<uintptr_t>(fpyr + (q.lvl - 15u * (uint32_t)q.pitch - 16u));
-        const uint8_t* ga = reinterpret_cast<const uint8_t*>(g0 & ~(uintptr_t)3);
-        const uint32_t t = __umul24(row, q.pitch) + (16u * half + ((uint32_t)g0 & 3u));
-        csh[kk] = t & 3u;
-        c4[kk] = *reinterpret_cast<const u32x4*>(ga + (t & ~3u));
-        c1[kk] = *reinterpret_cast<const uint32_t*>(ga + (t & ~3u) + 16);
-      }
+      // first byte: column -16 (left half, weight 0) or 0 (right half) of row `row` - 15, as the
+      // slab pointer plus a 32-bit offset; the address is cut to a dword boundary and the bytes are
+      // shifted into place afterwards.  An empty slot reads the start of the slab (and is not used).
+      const uint32_t lv = q.ok ? q.lvl - 15u * (uint32_t)q.pitch - 16u : 0u;
+      const uint32_t d = ((uint32_t)reinterpret_cast<uintptr_t>(fpyr) + lv) & 3u;
+      const uint32_t t = __umul24(row, q.pitch) + (16u * half + d);
+      const uint8_t* g = fpyr + ((lv - d) + (t & ~3u));
+      csh[kk] = t & 3u;
+      c4[kk] = *reinterpret_cast<const u32x4*>(g);
+      c1[kk] = *reinterpret_cast<const uint32_t*>(g + 16);
       if (kk == 0) {  // the first keypoint's patches are on their way while the moments are summed
         cur = q;
         if (q.ok) st = issue(q);
       }
     }
     int m10_v = 0, m01_v = 0;
+    int part[2 * KPW];  // per lane: its share of keypoint kk's m10 (entry 2 kk) and m01 (2 kk + 1)
 #pragma unroll
     for (int kk = 0; kk < KPW; kk++) {
-      if (!cok[kk]) continue;
       const uint32_t sh = csh[kk];
       const uint32_t y0 = __builtin_amdgcn_alignbyte(c4[kk].y, c4[kk].x, sh), y1 = __builtin_amdgcn_alignbyte(c4[kk].z, c4[kk].y, sh);
       const uint32_t y2 = __builtin_amdgcn_alignbyte(c4[kk].w, c4[kk].z, sh), y3 = __builtin_amdgcn_alignbyte(c1[kk], c4[kk].w, sh);
@@ -1707,10 +1704,51 @@ __global__ __launch_bounds__(D_THREADS) void orient_desc_kernel(const uint8_t* _
       s1 = __builtin_amdgcn_udot4(y1, w1.y, s1, false);
       s1 = __builtin_amdgcn_udot4(y2, w1.z, s1, false);
       s1 = __builtin_amdgcn_udot4(y3, w1.w, s1, false);
-      const int m10 = wave_sum(half ? (int)su : -(int)su);
-      const int m01 = wave_sum((row - 15) * (int)s1);
-      if (lane == kk) m10_v = m10;
-      if (lane == kk) m01_v = m01;
+      part[2 * kk] = half ? (int)su : -(int)su;
+      part[2 * kk + 1] = __mul24(row - 15, (int)s1);
+    }
+    if constexpr (KPW == 8) {
+      // Sixteen sums over the wavefront at once.  Each step adds lanes a fixed pattern apart and
+      // halves the number of registers: the sum that a register carries on is kept only in the
+      // lanes that the step's pattern leaves to it (two registers share one afterwards).  The
+      // first two steps act on the four groups of four lanes of a row of 16 and write under a
+      // group mask; the two within a group select by lane; the rows are added last.
+#define ORB_DPP_ADD_BANKS(R, Y, CTRL, BANKS) \
+  asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" BANKS : "+v"(R) : "v"(Y))
+      int r8[8], r4[4], r2[2];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {  // lane i + lane 15 - i: groups 0, 1 keep entry 2 i, groups 2, 3 entry 2 i + 1
+        r8[i] = part[2 * i] + __builtin_amdgcn_update_dpp(0, part[2 * i], 0x140, 0xF, 0xF, false);  // row_mirror
+        ORB_DPP_ADD_BANKS(r8[i], part[2 * i + 1], "row_mirror", "0xc");
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // lane i + lane 7 - i of each half row: groups 1, 3 keep r8[2 i], groups 0, 2 r8[2 i + 1]
+        r4[i] = r8[2 * i] + __builtin_amdgcn_update_dpp(0, r8[2 * i], 0x141, 0xF, 0xF, false);  // row_half_mirror
+        ORB_DPP_ADD_BANKS(r4[i], r8[2 * i + 1], "row_half_mirror", "0x5");
+      }
+#undef ORB_DPP_ADD_BANKS
+      const bool up2 = (lane & 2) != 0, up1 = (lane & 1) != 0;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {  // lanes two apart: lanes 0, 1 of a group keep r4[2 i], lanes 2, 3 r4[2 i + 1]
+        const int keep = up2 ? r4[2 * i + 1] : r4[2 * i], give = up2 ? r4[2 * i] : r4[2 * i + 1];
+        r2[i] = keep + __builtin_amdgcn_update_dpp(0, give, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+      }
+      const int keep = up1 ? r2[1] : r2[0], give = up1 ? r2[0] : r2[1];
+      int tot = keep + __builtin_amdgcn_update_dpp(0, give, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+      tot += __builtin_amdgcn_ds_bpermute(4 * (lane ^ 16), tot);
+      tot += __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), tot);
+      // Lane 4 b + 2 q1 + q0 of a row now holds entry 8 q0 + 4 q1 + {2, 0, 3, 1}[b]; lane kk takes
+      // entries 2 kk and 2 kk + 1 (the two tables list the lanes that hold them, a nibble per kk).
+      const uint32_t sa = (0x37152604u >> (4 * (lane & 7))) & 15u, sb = (0xBF9DAE8Cu >> (4 * (lane & 7))) & 15u;
+      m10_v = __builtin_amdgcn_ds_bpermute(4 * (int)sa, tot);
+      m01_v = __builtin_amdgcn_ds_bpermute(4 * (int)sb, tot);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KPW; kk++) {
+        const int m10 = wave_sum(part[2 * kk]), m01 = wave_sum(part[2 * kk + 1]);
+        if (lane == kk) m10_v = m10;
+        if (lane == kk) m01_v = m01;
+      }
     }
     steer(m01_v, m10_v, ang_v, cos_v, sin_v);
     // the keypoint records (epilogue of operator(): level coordinates scaled to the image), lane j's own
