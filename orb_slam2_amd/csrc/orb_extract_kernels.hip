@@ -1417,7 +1417,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 constexpr int D_THREADS = 256;
 constexpr int D_KPW = 8;        // keypoints per wavefront (batches)
-constexpr int D_KPW_SMALL = 1;  // ... when a launch holds only a few frames: more, shorter wavefronts
+constexpr int D_KPW_SMALL = 4;  // ... when a launch holds only a few frames: more, shorter wavefronts
 constexpr int D_RAW_ROWS = 32, D_BLR_ROWS = 48, D_PITCH = 64;  // staged rows (16 per load instruction), bytes per row
 constexpr int D_PAD = 16;                 // bytes in front of the level patch: its row 0 is read from offset -1
 // Fused form (the blurred patch is made in LDS from the level, no blurred level in memory):
