@@ -260,6 +260,49 @@ def test_device_resident_path_and_reuse(oracle):
             check_against(kp, d_d[f, :cnt[f]].cpu().numpy(), rk, rd)
 
 
+@pytest.mark.parametrize("n", [3, 11])
+def test_device_path_with_short_output_arrays(n):
+    """max_kp below the number of keypoints found: the first max_kp keypoints and descriptors are
+    written, nothing beyond them, and d_n_out still holds the number found (small launches take
+    four keypoints per wavefront, larger ones eight)."""
+    import torch
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd._lib import KP_DTYPE
+    from orb_slam2_amd.synth import synth_sequence
+    dev = torch.device("cuda", 0)
+    rows, cols = 240, 320
+    seq = synth_sequence(rows, cols, n, seed=50 + n)
+    ex = ORBextractor(600, 1.2, 8, 20, 7)
+    fk, fd = ex.extract_batch(seq)
+    d_img = torch.from_numpy(seq).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for cap in (601, 333, 8, 1):
+        d_k = torch.full((n, cap + 4, 6), -7.0, dtype=torch.float32, device=dev)
+        d_d = torch.full((n, cap + 4, 32), 0xAB, dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(n, dtype=torch.int32, device=dev)
+        # arrays of cap + 4 rows per frame, of which the library may write cap
+        ex.extract_batch_device(d_img.data_ptr(), n, rows, cols, d_k.data_ptr(), d_d.data_ptr(), d_n.data_ptr(), cap + 4,
+                                stream=st)
+        torch.cuda.synchronize()
+        full_k, full_d = d_k.cpu().numpy().copy(), d_d.cpu().numpy().copy()
+        d_k.fill_(-7.0); d_d.fill_(0xAB)
+        ex2 = ORBextractor(600, 1.2, 8, 20, 7)
+        d_k2 = torch.full((n, cap, 6), -7.0, dtype=torch.float32, device=dev)
+        d_d2 = torch.full((n, cap, 32), 0xAB, dtype=torch.uint8, device=dev)
+        ex2.extract_batch_device(d_img.data_ptr(), n, rows, cols, d_k2.data_ptr(), d_d2.data_ptr(), d_n.data_ptr(), cap,
+                                 stream=st)
+        torch.cuda.synchronize()
+        cnt = d_n.cpu().numpy()
+        for f in range(n):
+            assert cnt[f] == len(fk[f]) and cnt[f] > cap - 300
+            m = min(cap, cnt[f])
+            got = d_k2[f].cpu().numpy().copy().view(KP_DTYPE).reshape(-1)
+            assert np.array_equal(got[:m], fk[f][:m]) and np.array_equal(d_d2[f, :m].cpu().numpy(), fd[f][:m])
+            assert (d_k2[f, m:].cpu().numpy() == -7.0).all() and (d_d2[f, m:].cpu().numpy() == 0xAB).all()
+            mm = min(cap + 4, cnt[f])
+            assert (full_k[f, mm:] == -7.0).all() and (full_d[f, mm:] == 0xAB).all()
+
+
 def test_full_size_properties_batch():
     """Properties that hold at the benchmark's batch size without the oracle: every frame of
     a batch of identical images gives identical output; output is level-major; keypoints
@@ -307,7 +350,7 @@ def test_blur_fused_into_descriptors(oracle, compat):
     """The descriptor kernel blurs each keypoint's patch in on-chip memory by default; with the
     levels blurred to memory first (set_blur_fusion(False), the reference's order) keypoints and
     descriptors are bit-identical, for both tap sets (the one summing to 257 saturates), single
-    frames (one keypoint per wavefront) and batches (four), at image borders and with bright
+    frames and small batches (four keypoints per wavefront) and batches (eight), at image borders and with bright
     patches that make the saturation matter."""
     from orb_slam2_amd import ORBextractor
     from orb_slam2_amd.synth import synth_sequence
