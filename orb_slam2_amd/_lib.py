@@ -7,6 +7,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbhip.so")
+if os.environ.get("ORBHIP_LIB"):  # another build of the library (development: timing builds side by side)
+    LIB_PATH = os.environ["ORBHIP_LIB"]
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_CAPACITY = 0, -1, -2, -3, -4
 
