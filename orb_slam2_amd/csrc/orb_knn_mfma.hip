@@ -1,10 +1,14 @@
 // Brute-force Hamming kNN-2 on the matrix cores of gfx950.
 //
-// With every descriptor bit b mapped to s = 2b - 1 (+1 / -1 as int8), the dot product of two
-// descriptors is (#equal bits) - (#different bits) = 256 - 2 * hamming, an exact integer.  So
-// the 1M x 1M distance table is an int8 GEMM with K = 256, which v_mfma_i32_32x32x32_i8 does at
-// 1024 multiply-adds per cycle and SIMD - the popcount form needs 16 vector instructions per
-// pair.  Results are the same integers as the popcount kernel's (orb_match.hip: knn2_kernel),
+// With the bits of a database row as 0 / 1 and the bits of a query as -1 / +1 (int8), the dot
+// product of the two is (#bits set in both) - (#bits set in the row only), and
+//   hamming = (#bits set in the query) - dot,
+// an exact integer.  So the 1M x 1M distance table is an int8 GEMM with K = 256, which
+// v_mfma_i32_32x32x32_i8 does at 1024 multiply-adds per cycle and SIMD - the popcount form needs
+// 16 vector instructions per pair.  (Both operands as -1 / +1 give 256 - 2 * hamming just as
+// well; but the matrix cores' clock depends on how many operand bits change from one instruction
+// to the next, and the streamed operand as 0x00 / 0x01 instead of 0xFF / 0x01 runs 3 % faster.)
+// Results are the same integers as the popcount kernel's (orb_match.hip: knn2_kernel),
 // including the tie rule (first minimum = lowest database row).
 //
 // Work decomposition: a wavefront owns KM_QT tiles of 32 queries as the B operand, expanded
@@ -32,14 +36,15 @@ constexpr int KM_QT = 4;               // query tiles (of 32) per wavefront
 constexpr int KM_QPW = 32 * KM_QT;     // queries per wavefront
 constexpr int KM_QPB = KM_QPW * (KM_THREADS / 64);
 constexpr int KM_EARLY = 3;            // A fragments requested before the expansion of the next tile
-constexpr int KM_ROWBITS = 21;         // key = (256 - dot) << 21 | row; 256 - dot = 2 * distance <= 512
+constexpr int KM_ROWBITS = 21;         // key = (256 - dot) << 21 | row; 256 - dot <= 512
 constexpr int KM_CHUNK = 1 << KM_ROWBITS;
 
-// 16 descriptor bits -> 16 bytes of +1 (bit set) / -1, byte i of dword d = bit 4d + i.
+// 16 descriptor bits -> 16 bytes of +1 (bit set) / CLEAR (-1 or 0), byte i of dword d = bit 4d + i.
 // The multiplication puts bit i of a nibble at bit 2 of byte i, i.e. a v_perm selector byte of
-// 4 (first byte of 0x01010101) or 0 (first byte of 0xFFFFFFFF); rows past the end of the
+// 4 (first byte of 0x01010101) or 0 (first byte of CLEAR); rows past the end of the
 // database get selector 0x0c everywhere (constant 0): their dot products are 0 and they are
 // skipped by index.
+template <uint32_t CLEAR>  // the four bytes that stand for clear bits: 0xFFFFFFFF (-1) or 0
 __device__ __forceinline__ km_v4i expand16(uint32_t bits, bool valid) {
   const uint32_t off = valid ? 0u : 0x0c0c0c0cu;
   km_v4i r;
@@ -47,7 +52,7 @@ __device__ __forceinline__ km_v4i expand16(uint32_t bits, bool valid) {
   for (int d = 0; d < 4; d++) {
     const uint32_t x = (bits >> (4 * d)) & 15u;
     const uint32_t sel = ((x * 0x00810204u) & 0x04040404u) | off;
-    r[d] = (int)__builtin_amdgcn_perm(0x01010101u, 0xFFFFFFFFu, sel);
+    r[d] = (int)__builtin_amdgcn_perm(0x01010101u, CLEAR, sel);
   }
   return r;
 }
@@ -60,17 +65,28 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
   // A fragments of one 32-row tile: [group g = 2 * kstep + half][row][16 bytes], three buffers
   // used in turn (tile % 3)
   __shared__ __attribute__((aligned(16))) km_v4i s_a[3][16 * 32];
-  // 8 descriptor bits -> 8 bytes of +1 / -1; entry 256 (all zero) stands for rows past the end
+  // 8 descriptor bits -> 8 bytes of 1 / 0; entry 256 (all zero) stands for rows past the end
   __shared__ __attribute__((aligned(8))) uint2 s_lut[257];
+  __shared__ int s_pq[KM_THREADS / 64][KM_QT][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int qbase = blockIdx.x * KM_QPB + wave * KM_QPW;
 
   for (int i = tid; i < 257; i += KM_THREADS) {
-    const km_v4i e = expand16((uint32_t)i, i < 256);
+    const km_v4i e = expand16<0u>((uint32_t)i, i < 256);
     s_lut[i] = make_uint2((uint32_t)e[0], (uint32_t)e[1]);
   }
   __syncthreads();
+  // set bits of the wave's queries (used when a chunk's keys are turned into distances; kept in LDS,
+  // the registers are full)
+#pragma unroll
+  for (int t = 0; t < KM_QT; t++) {
+    const uint4* qp = reinterpret_cast<const uint4*>(q16 + (size_t)min(qbase + 32 * t + r, nq - 1) * 16);
+    const uint4 u = qp[h];
+    const int half = __popc(u.x) + __popc(u.y) + __popc(u.z) + __popc(u.w);
+    const int pq = half + __shfl_xor(half, 32, 64);
+    if (h == 0) s_pq[wave][t][r] = pq;
+  }
   // B operand: the wave's queries, expanded once.  Lane (r, h) holds for tile t and K-step s
   // the 16 bits 32 s + 16 h .. + 15 of query qbase + 32 t + r - the same bit -> k order as the
   // A fragments below, which is all the dot product needs.
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
   for (int t = 0; t < KM_QT; t++) {
     const int qi = min(qbase + 32 * t + r, nq - 1);
 #pragma unroll
-    for (int s = 0; s < 8; s++) b[t][s] = expand16(q16[(size_t)qi * 16 + 2 * s + h], true);
+    for (int s = 0; s < 8; s++) b[t][s] = expand16<0xFFFFFFFFu>(q16[(size_t)qi * 16 + 2 * s + h], true);
   }
   int bd[KM_QT], sd[KM_QT], bi[KM_QT];
 #pragma unroll
@@ -176,8 +192,10 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
       const uint32_t m1 = min(k1[t], o1);
       const uint32_t m2 = min(max(k1[t], o1), min(k2[t], o2));
       // fold the chunk into the running (best, second, index): an earlier chunk keeps ties
-      const int cb = m1 == 0xFFFFFFFFu ? 256 : (int)(m1 >> (KM_ROWBITS + 1));
-      const int cs = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> (KM_ROWBITS + 1));
+      // keys hold 256 - dot; distance = (set bits of the query) - dot
+      const int pq = s_pq[wave][t][r];
+      const int cb = m1 == 0xFFFFFFFFu ? 256 : (int)(m1 >> KM_ROWBITS) - (256 - pq);
+      const int cs = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> KM_ROWBITS) - (256 - pq);
       const int ci = (int)(m1 & (KM_CHUNK - 1)) + cbase;
       if (cb < bd[t]) { sd[t] = min(bd[t], cs); bd[t] = cb; bi[t] = ci; }
       else sd[t] = min(sd[t], cb);
