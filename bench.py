@@ -356,9 +356,9 @@ def main():
             stages["orient_desc"] = round(stages["orient_desc"] + stages.pop("blur"), 4)
         stages["search_by_projection"] = round(match_ms, 4)
         gbs = {k: ab[k] * B / (stages[k] * 1e-3) / 1e9 for k in ab}
-        # the roofline object is for the stage that reads every pixel through one kernel and is slowest
-        # against its bytes: FAST or the pyramid (the descriptor kernel gathers patches: see stage_gbs)
-        dom = max(("pyramid", "fast"), key=lambda k: stages[k])
+        # the roofline object is for the stage that streams every pixel and is furthest below its
+        # roofline: FAST or the pyramid (the descriptor kernel gathers patches: see stage_gbs)
+        dom = min(("pyramid", "fast"), key=lambda k: gbs[k])
         out = {
             "metric": "ORB frames/s (1241x376, 2000kp, 8 lvl) + Hamming kNN-2 matches/s at 1-8 GPU",
             "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
