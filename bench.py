@@ -302,6 +302,17 @@ def main():
         tc = time.perf_counter() - tc0
         cpu = {"value": round(n / tc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames of the same sequence: oracle extraction + SearchByProjection on consecutive pairs" % n}
+        # the same sample frame-parallel on the host's cores (16 on the one-GPU box; os.cpu_count() there is
+        # the whole machine's): a fairer CPU figure than one core, still the plain restatement
+        from oracle.chain_ref import chain_reference_parallel
+        nthreads = int(os.environ.get("ORBHIP_CPU_THREADS", "16"))
+        tp0 = time.perf_counter()
+        frames_p, pairs_p = chain_reference_parallel(chain.scene, seq[:n], NFEAT, NLEVELS, threads=nthreads)
+        tpar = time.perf_counter() - tp0
+        same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(frames, frames_p)) and \
+            all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(pairs_ref, pairs_p))
+        cpu["parallel"] = {"value": round(n / tpar, 2), "unit": "frames/s", "cores": nthreads, "kind": "port",
+                           "identical_to_one_core": bool(same)}
         # what the timed chain left on the GPU against what the oracle just computed for the same frames
         g_nout, g_kps, g_desc, g_match, g_nm = chain.results((args.steps - 1) % nsets if args.steps > 0 else 0)
         bad_frames = bad_pairs = 0

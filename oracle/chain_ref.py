@@ -31,3 +31,24 @@ def chain_reference(scene, seq, nfeatures=2000, nlevels=8, first_frame=0, th=7.0
             pairs.append(match_pair(scene, sf, pk, pd, kps, desc, first_frame + k - 1, th, check_ori))
         frames.append((kps, desc))
     return frames, pairs
+
+
+def chain_reference_parallel(scene, seq, nfeatures=2000, nlevels=8, threads=16, th=7.0, check_ori=True):
+    """The same work frame-parallel on `threads` host threads (the oracle's C functions hold no state
+    and run outside the interpreter lock): every frame extracted by some thread, then every pair
+    matched by some thread.  Returns the same (frames, pairs) as chain_reference."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    local = threading.local()
+
+    def extractor():
+        if not hasattr(local, "ref"):
+            local.ref = O.Extractor(nfeatures, 1.2, nlevels, 20, 7)
+        return local.ref
+
+    sf = O.Extractor(nfeatures, 1.2, nlevels, 20, 7).tables()["scale"]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        frames = list(pool.map(lambda k: extractor()(seq[k], None), range(len(seq))))
+        pairs = list(pool.map(lambda p: match_pair(scene, sf, frames[p][0], frames[p][1], frames[p + 1][0], frames[p + 1][1],
+                                                   p, th, check_ori), range(len(seq) - 1)))
+    return frames, pairs
