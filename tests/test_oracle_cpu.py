@@ -427,3 +427,18 @@ def test_opencv_release_switch_taps_and_grey_weights(oracle):
     finally:
         oracle.set_opencv_compat(4, 5)
     assert list(oracle.gaussian_taps()) == [18, 34, 48, 56, 48, 34, 18]
+
+
+def test_frame_parallel_chain_equals_the_sequential_one():
+    """bench.py's all-cores CPU leg: frames and pairs handed to threads give what the plain loop gives."""
+    from oracle.chain_ref import chain_reference, chain_reference_parallel
+    from orb_slam2_amd.synth import SequenceScene, synth_sequence
+    seq = synth_sequence(120, 200, 5, seed=3, step=2)
+    sc = SequenceScene(120, 200)
+    f1, p1 = chain_reference(sc, seq, 300, 4)
+    f2, p2 = chain_reference_parallel(sc, seq, 300, 4, threads=3)
+    assert len(f1) == len(f2) == 5 and len(p1) == len(p2) == 4
+    for a, b in zip(f1, f2):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for a, b in zip(p1, p2):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
