@@ -144,24 +144,42 @@ ORC_API int orc_fast9_16(const uint8_t* img, int w, int h, int stride, int thres
   if (threshold > 255) threshold = 255;
   if (w < 7 || h < 7) return 0;
   uint8_t* score = (uint8_t*)calloc((size_t)w * h, 1);
+  int ring[16];
+  for (int k = 0; k < 16; k++) ring[k] = k_circle[k][1] * stride + k_circle[k][0];
   for (int y = 3; y < h - 3; y++) {
     for (int x = 3; x < w - 3; x++) {
       const uint8_t* p = img + (size_t)y * stride + x;
       int v = p[0];
-      int pix[25], d[25];
-      for (int k = 0; k < 25; k++) {
-        pix[k] = p[k_circle[k % 16][1] * stride + k_circle[k % 16][0]];
-        d[k] = v - pix[k];
+      {
+        /* Early out, as cv::FAST has one: nine contiguous ring pixels take in ring pixel 0 or 8 and
+         * ring pixel 4 or 12, so a corner needs one of each pair beyond the threshold on the same
+         * side.  (A necessary condition only: what passes is decided by the full test below.) */
+        const int hi = v + threshold, lo = v - threshold;
+        const int p0 = p[3 * stride], p8 = p[-3 * stride], p4 = p[3], p12 = p[-3];
+        const int brighter = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi);
+        const int darker = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo);
+        if (!brighter && !darker) continue;
       }
-      int corner = 0, count = 0;
-      for (int k = 0; k < 25 && !corner; k++) { /* darker arc: p < v - t */
-        if (pix[k] < v - threshold) { if (++count > 8) corner = 1; } else count = 0;
+      /* ring pixels darker than v - t resp. brighter than v + t as two 16-bit masks (bit k = ring
+       * pixel k), each written twice in a row so that an arc may wrap; bit i of run9() = ring pixels
+       * i .. i + 8 all set */
+      int pix[16];
+      uint32_t md = 0, mb = 0;
+      for (int k = 0; k < 16; k++) {
+        pix[k] = p[ring[k]];
+        md |= (uint32_t)(pix[k] < v - threshold) << k;
+        mb |= (uint32_t)(pix[k] > v + threshold) << k;
       }
-      count = 0;
-      for (int k = 0; k < 25 && !corner; k++) { /* brighter arc: p > v + t */
-        if (pix[k] > v + threshold) { if (++count > 8) corner = 1; } else count = 0;
+      md |= md << 16; mb |= mb << 16;
+      uint32_t rd = md & (md >> 1), rb = mb & (mb >> 1);
+      rd &= rd >> 2; rb &= rb >> 2;
+      rd &= rd >> 4; rb &= rb >> 4;
+      rd &= md >> 8; rb &= mb >> 8;
+      if (((rd | rb) & 0xFFFFu) != 0) {
+        int d[25];
+        for (int k = 0; k < 25; k++) d[k] = v - pix[k % 16];
+        score[(size_t)y * w + x] = (uint8_t)fast_corner_score(d, threshold);
       }
-      if (corner) score[(size_t)y * w + x] = (uint8_t)fast_corner_score(d, threshold);
     }
   }
   int n = 0;
@@ -221,19 +239,28 @@ ORC_API void orc_gaussian_blur_7x7(const uint8_t* src, int w, int h, int sstride
   int taps[7];
   orc_gaussian_taps_7_s2(taps);
   uint16_t* hbuf = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)w * h);
-  for (int y = 0; y < h; y++)
+  /* (pixels three or more from the border take their taps without the reflection: the same sums) */
+  for (int y = 0; y < h; y++) {
+    const uint8_t* S = src + (size_t)y * sstride;
     for (int x = 0; x < w; x++) {
       uint32_t acc = 0;
-      for (int i = 0; i < 7; i++) acc += (uint32_t)taps[i] * src[(size_t)y * sstride + refl101(x + i - 3, w)];
+      if (x >= 3 && x < w - 3)
+        for (int i = 0; i < 7; i++) acc += (uint32_t)taps[i] * S[x + i - 3];
+      else
+        for (int i = 0; i < 7; i++) acc += (uint32_t)taps[i] * S[refl101(x + i - 3, w)];
       hbuf[(size_t)y * w + x] = (uint16_t)(acc > 0xFFFF ? 0xFFFF : acc);
     }
-  for (int y = 0; y < h; y++)
+  }
+  for (int y = 0; y < h; y++) {
+    const uint16_t* R[7];
+    for (int i = 0; i < 7; i++) R[i] = hbuf + (size_t)refl101(y + i - 3, h) * w;
     for (int x = 0; x < w; x++) {
       uint32_t acc = 0;
-      for (int i = 0; i < 7; i++) acc += (uint32_t)taps[i] * hbuf[(size_t)refl101(y + i - 3, h) * w + x];
+      for (int i = 0; i < 7; i++) acc += (uint32_t)taps[i] * R[i][x];
       uint32_t v = (acc + (1u << 15)) >> 16;
       dst[(size_t)y * dstride + x] = (uint8_t)(v > 255 ? 255 : v);
     }
+  }
   free(hbuf);
 }
 
