@@ -39,17 +39,21 @@ __global__ __launch_bounds__(256) void ktile(int* out, int seed, int iters, long
   v4i b[4][8];
   for (int t = 0; t < 4; t++)
     for (int s = 0; s < 8; s++) b[t][s] = v4i{seed * (t + 1), s * 5 + seed, 7 + t, (int)threadIdx.x * 9 + s};
-  if (DISTINCT_B == 2) {
-    // operands of +1 / -1 bytes with random signs, as in the kNN-2 kernel
+  // 2: A and B of random +1 / -1 bytes; 3: A of random 0 / 1 bytes, B of +1 / -1 (the kNN-2 kernel);
+  // 4: A of random 0 / 2 bytes, B of 0 / 1
+  constexpr unsigned A_LO = DISTINCT_B == 2 ? 0xFFu : 0x00u, A_HI = DISTINCT_B == 4 ? 0x02u : 0x01u;
+  constexpr unsigned B_LO = DISTINCT_B == 4 ? 0x00u : 0xFFu, B_HI = 0x01u;
+  constexpr unsigned A_X = (A_LO ^ A_HI) * 0x01010101u;
+  if (DISTINCT_B >= 2) {
     unsigned x = seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x * 69069u;
-    auto pm = [&]() {
+    auto pm = [&](unsigned lo, unsigned hi) {
       unsigned r = 0;
-      for (int i = 0; i < 4; i++) { x = x * 1664525u + 1013904223u; r |= ((x >> 16) & 1 ? 0x01u : 0xFFu) << (8 * i); }
+      for (int i = 0; i < 4; i++) { x = x * 1664525u + 1013904223u; r |= ((x >> 16) & 1 ? hi : lo) << (8 * i); }
       return (int)r;
     };
     for (int t = 0; t < 4; t++)
-      for (int s = 0; s < 8; s++) b[t][s] = v4i{pm(), pm(), pm(), pm()};
-    a = v4i{pm(), pm(), pm(), pm()};
+      for (int s = 0; s < 8; s++) b[t][s] = v4i{pm(B_LO, B_HI), pm(B_LO, B_HI), pm(B_LO, B_HI), pm(B_LO, B_HI)};
+    a = v4i{pm(A_LO, A_HI), pm(A_LO, A_HI), pm(A_LO, A_HI), pm(A_LO, A_HI)};
   }
   const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int sum = 0;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void ktile(int* out, int seed, int iters, long
         sum += m;
       }
     }
-    if (DISTINCT_B == 2) { a[0] = ~a[0] + 1 + ((sum & 1) << 30); a[2] ^= 0xFE00FE00; }  // signs keep changing
+    if (DISTINCT_B >= 2) { a[0] ^= A_X; a[1] ^= (sum & 1) ? A_X : 0u; a[2] ^= A_X & 0xFF00FF00u; }  // the bytes keep changing
     else a[0] += sum & 1;
   }
   out[blockIdx.x * 256 + threadIdx.x] = sum;
@@ -127,6 +131,8 @@ int main() {
   }
   if (run_tile<1, 16>("tile: 32 B operands, max of 16, long run", 2, 200000)) return 1;
   if (run_tile<2, 16>("tile: random +1/-1 operands, max of 16, long run", 2, 200000)) return 1;
+  if (run_tile<3, 16>("tile: A random 0/1, B random +1/-1, max of 16, long run", 2, 200000)) return 1;
+  if (run_tile<4, 16>("tile: A random 0/2, B random 0/1, max of 16, long run", 2, 200000)) return 1;
   if (run<4>("4 accumulators, long run", 2, 240000)) return 1;
   for (int w = 1; w <= 4; w *= 2) {
     if (run<4>("4 independent accumulators", w, 20000)) return 1;
