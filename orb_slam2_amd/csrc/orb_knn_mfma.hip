@@ -1,13 +1,16 @@
 // Brute-force Hamming kNN-2 on the matrix cores of gfx950.
 //
-// With the bits of a database row as 0 / 1 and the bits of a query as -1 / +1 (int8), the dot
-// product of the two is (#bits set in both) - (#bits set in the row only), and
-//   hamming = (#bits set in the query) - dot,
+// With the bits of a database row as 0 / 2 and the bits of a query as 0 / 1 (int8), the dot
+// product of the two is 2 * (#bits set in both); started from -(#bits set in the row) instead of
+// from zero, the accumulator ends at  acc = 2 * both - row,  and
+//   hamming = query + row - 2 * both = (#bits set in the query) - acc,
 // an exact integer.  So the 1M x 1M distance table is an int8 GEMM with K = 256, which
 // v_mfma_i32_32x32x32_i8 does at 1024 multiply-adds per cycle and SIMD - the popcount form needs
-// 16 vector instructions per pair.  (Both operands as -1 / +1 give 256 - 2 * hamming just as
-// well; but the matrix cores' clock depends on how many operand bits change from one instruction
-// to the next, and the streamed operand as 0x00 / 0x01 instead of 0xFF / 0x01 runs 3 % faster.)
+// 16 vector instructions per pair.  (Both operands as -1 / +1 give 256 - 2 * hamming with no
+// start values at all; but the matrix cores' clock depends on how many operand bits change from
+// one instruction to the next and on how many products are zero: tools/ubench/mfma_rate.hip
+// sustains 3703 TOP/s on random -1 / +1 operands, 3928 with one operand as 0 / 1 and 4562 with
+// 0 / 2 against 0 / 1; this kernel went from 0.1746 to 0.169 s with the first change.)
 // Results are the same integers as the popcount kernel's (orb_match.hip: knn2_kernel),
 // including the tie rule (first minimum = lowest database row).
 //
@@ -39,12 +42,12 @@ constexpr int KM_EARLY = 3;            // A fragments requested before the expan
 constexpr int KM_ROWBITS = 21;         // key = (256 - dot) << 21 | row; 256 - dot <= 512
 constexpr int KM_CHUNK = 1 << KM_ROWBITS;
 
-// 16 descriptor bits -> 16 bytes of +1 (bit set) / CLEAR (-1 or 0), byte i of dword d = bit 4d + i.
+// 16 descriptor bits -> 16 bytes of SET / CLEAR, byte i of dword d = bit 4d + i.
 // The multiplication puts bit i of a nibble at bit 2 of byte i, i.e. a v_perm selector byte of
-// 4 (first byte of 0x01010101) or 0 (first byte of CLEAR); rows past the end of the
+// 4 (first byte of SET) or 0 (first byte of CLEAR); rows past the end of the
 // database get selector 0x0c everywhere (constant 0): their dot products are 0 and they are
 // skipped by index.
-template <uint32_t CLEAR>  // the four bytes that stand for clear bits: 0xFFFFFFFF (-1) or 0
+template <uint32_t SET, uint32_t CLEAR>  // four bytes each: what a set and a clear bit become
 __device__ __forceinline__ km_v4i expand16(uint32_t bits, bool valid) {
   const uint32_t off = valid ? 0u : 0x0c0c0c0cu;
   km_v4i r;
@@ -52,7 +55,7 @@ __device__ __forceinline__ km_v4i expand16(uint32_t bits, bool valid) {
   for (int d = 0; d < 4; d++) {
     const uint32_t x = (bits >> (4 * d)) & 15u;
     const uint32_t sel = ((x * 0x00810204u) & 0x04040404u) | off;
-    r[d] = (int)__builtin_amdgcn_perm(0x01010101u, CLEAR, sel);
+    r[d] = (int)__builtin_amdgcn_perm(SET, CLEAR, sel);
   }
   return r;
 }
@@ -65,15 +68,21 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
   // A fragments of one 32-row tile: [group g = 2 * kstep + half][row][16 bytes], three buffers
   // used in turn (tile % 3)
   __shared__ __attribute__((aligned(16))) km_v4i s_a[3][16 * 32];
-  // 8 descriptor bits -> 8 bytes of 1 / 0; entry 256 (all zero) stands for rows past the end
+  // 8 descriptor bits -> 8 bytes of 2 / 0; entry 256 (all zero) stands for rows past the end
   __shared__ __attribute__((aligned(8))) uint2 s_lut[257];
   __shared__ int s_pq[KM_THREADS / 64][KM_QT][32];
+  // minus the set bits of the rows of a tile: the accumulators' start values.  Four sets in turn: the
+  // set of tile i + 2 is cleared during iteration i (last read in iteration i - 2), filled during
+  // iteration i + 1 and read in iteration i + 2.
+  __shared__ __attribute__((aligned(16))) int s_nrow[4][32];
+  // running (best, second, index) of the wave's queries over the chunks (the registers are full)
+  __shared__ int s_run[KM_THREADS / 64][KM_QT][3][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int qbase = blockIdx.x * KM_QPB + wave * KM_QPW;
 
   for (int i = tid; i < 257; i += KM_THREADS) {
-    const km_v4i e = expand16<0u>((uint32_t)i, i < 256);
+    const km_v4i e = expand16<0x02020202u, 0u>((uint32_t)i, i < 256);
     s_lut[i] = make_uint2((uint32_t)e[0], (uint32_t)e[1]);
   }
   __syncthreads();
@@ -95,15 +104,13 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
   for (int t = 0; t < KM_QT; t++) {
     const int qi = min(qbase + 32 * t + r, nq - 1);
 #pragma unroll
-    for (int s = 0; s < 8; s++) b[t][s] = expand16<0xFFFFFFFFu>(q16[(size_t)qi * 16 + 2 * s + h], true);
+    for (int s = 0; s < 8; s++) b[t][s] = expand16<0x01010101u, 0u>(q16[(size_t)qi * 16 + 2 * s + h], true);
   }
-  int bd[KM_QT], sd[KM_QT], bi[KM_QT];
 #pragma unroll
-  for (int t = 0; t < KM_QT; t++) { bd[t] = 256; sd[t] = 256; bi[t] = -1; }
+  for (int t = 0; t < KM_QT; t++) { s_run[wave][t][0][lane] = 256; s_run[wave][t][1][lane] = 256; s_run[wave][t][2][lane] = -1; }
 
   // the two work items (row, group) of this thread in the expansion of a tile
   const int er = tid & 31, eg0 = tid >> 5;  // groups eg0 and eg0 + 8
-  const km_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   for (int cbase = 0; cbase < ndb; cbase += KM_CHUNK) {
     const int cn = min(KM_CHUNK, ndb - cbase);
@@ -127,6 +134,10 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
       const uint2 c0 = s_lut[v ? (pk1 & 255u) : 256u], c1 = s_lut[v ? (pk1 >> 8) : 256u];
       buf[eg0 * 32 + er] = km_v4i{(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
       buf[(eg0 + 8) * 32 + er] = km_v4i{(int)c0.x, (int)c0.y, (int)c1.x, (int)c1.y};
+      // this thread's 32 bits of the row, counted into the row's start value
+      if (v) atomicSub(&s_nrow[tile & 3][er], __popc(pk0 & 0xFFFFu) + __popc(pk1 & 0xFFFFu));
+      // the set after the next one is cleared for its turn
+      if (tid < 32) s_nrow[(tile + 1) & 3][tid] = 0;
     };
     // In iteration i the first fragments of tile i (complete since the barrier of iteration
     // i - 1) are requested, tile i + 1 is expanded into the next buffer while they travel, and
@@ -134,7 +145,9 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
     // into iteration i + 1 writes tile i + 2, i.e. buffer (i + 2) % 3, which no read of tile i or
     // i + 1 touches; it cannot get further ahead than that, because the barrier of iteration
     // i + 1 waits for every wavefront to have finished iteration i.
+    if (tid < 64) s_nrow[tid >> 5][tid & 31] = 0;  // the sets of tiles 0 and 1
     fetch(0);
+    __syncthreads();
     expand(0, 0);
     if (ntiles > 1) fetch(1);
     __syncthreads();
@@ -145,6 +158,15 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
       km_v4i a[8];  // the first KM_EARLY fragments before the barrier, the others behind the first MFMAs
 #pragma unroll
       for (int s = 0; s < KM_EARLY; s++) a[s] = buf[(2 * s + h) * 32 + r];
+      // start values (complete since the barrier of the iteration before, like the first fragments):
+      // accumulator entry j belongs to row (j & 3) + 8 * (j >> 2) + 4 * h of the tile
+      km_v16i start;
+      {
+        const km_v4i* nr = reinterpret_cast<const km_v4i*>(&s_nrow[tile & 3][4 * h]);
+        const km_v4i n0 = nr[0], n1 = nr[2], n2 = nr[4], n3 = nr[6];
+        start = km_v16i{n0[0], n0[1], n0[2], n0[3], n1[0], n1[1], n1[2], n1[3],
+                        n2[0], n2[1], n2[2], n2[3], n3[0], n3[1], n3[2], n3[3]};
+      }
       if (tile + 1 < ntiles) {
         expand(tile + 1, slot);
         if (tile + 2 < ntiles) fetch(tile + 2);  // in flight during the MFMAs
@@ -158,7 +180,7 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
         for (int s = 0; s < 8; s++) {
 #pragma unroll
           for (int t = 0; t < KM_QT; t++)
-            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[t][s], s == 0 ? zero : acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[t][s], s == 0 ? start : acc[t], 0, 0, 0);
         }
         // acc[t][j] = dot(query of this lane in tile t, database row row0 + (j & 3) + 8 * (j >> 2))
         const int row0 = tile * 32 + 4 * h;
@@ -192,13 +214,15 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
       const uint32_t m1 = min(k1[t], o1);
       const uint32_t m2 = min(max(k1[t], o1), min(k2[t], o2));
       // fold the chunk into the running (best, second, index): an earlier chunk keeps ties
-      // keys hold 256 - dot; distance = (set bits of the query) - dot
+      // keys hold 256 - acc; distance = (set bits of the query) - acc
       const int pq = s_pq[wave][t][r];
       const int cb = m1 == 0xFFFFFFFFu ? 256 : (int)(m1 >> KM_ROWBITS) - (256 - pq);
       const int cs = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> KM_ROWBITS) - (256 - pq);
       const int ci = (int)(m1 & (KM_CHUNK - 1)) + cbase;
-      if (cb < bd[t]) { sd[t] = min(bd[t], cs); bd[t] = cb; bi[t] = ci; }
-      else sd[t] = min(sd[t], cb);
+      int bd = s_run[wave][t][0][lane], sd = s_run[wave][t][1][lane], bi = s_run[wave][t][2][lane];
+      if (cb < bd) { sd = min(bd, cs); bd = cb; bi = ci; }
+      else sd = min(sd, cb);
+      s_run[wave][t][0][lane] = bd; s_run[wave][t][1][lane] = sd; s_run[wave][t][2][lane] = bi;
     }
   }
   if (h == 0) {
@@ -206,10 +230,11 @@ __global__ __launch_bounds__(KM_THREADS) void knn2_mfma_kernel(const uint16_t* _
     for (int t = 0; t < KM_QT; t++) {
       const int qi = qbase + 32 * t + r;
       if (qi < nq) {
-        out_best[qi] = bd[t];
-        out_second[qi] = sd[t];
-        out_idx[qi] = bi[t] < 0 ? -1 : bi[t] + index_base;
-        if (out_accept) out_accept[qi] = (uint8_t)(bi[t] >= 0 && (float)bd[t] < __fmul_rn(ratio, (float)sd[t]));
+        const int bd = s_run[wave][t][0][lane], sd = s_run[wave][t][1][lane], bi = s_run[wave][t][2][lane];
+        out_best[qi] = bd;
+        out_second[qi] = sd;
+        out_idx[qi] = bi < 0 ? -1 : bi + index_base;
+        if (out_accept) out_accept[qi] = (uint8_t)(bi >= 0 && (float)bd < __fmul_rn(ratio, (float)sd));
       }
     }
   }
