@@ -19,7 +19,7 @@
 // LDS 32 at a time: the workgroup expands the packed 32 x 32 bytes to 32 x 256 int8 (through a
 // byte -> 8 bytes table in LDS; three buffers in turn, one barrier per tile) in the fragment order of
 // the A operand, every wavefront reads the eight A fragments (one ds_read_b128 each; the first
-// three are requested before the next tile is expanded, so that the MFMAs can start right after
+// four are requested before the next tile is expanded, so that the MFMAs can start right after
 // the barrier) and issues 8 * KM_QT MFMAs.  In the
 // 32x32 result a lane holds one query (column) and 16 database rows; it keeps the two
 // smallest (distance, row) keys of its rows, lanes l and l + 32 (same query, other rows) are
@@ -38,7 +38,7 @@ constexpr int KM_THREADS = 256;        // 4 wavefronts
 constexpr int KM_QT = 4;               // query tiles (of 32) per wavefront
 constexpr int KM_QPW = 32 * KM_QT;     // queries per wavefront
 constexpr int KM_QPB = KM_QPW * (KM_THREADS / 64);
-constexpr int KM_EARLY = 3;            // A fragments requested before the expansion of the next tile
+constexpr int KM_EARLY = 4;            // A fragments requested before the expansion of the next tile
 constexpr int KM_ROWBITS = 21;         // key = (256 - dot) << 21 | row; 256 - dot <= 512
 constexpr int KM_CHUNK = 1 << KM_ROWBITS;
 
