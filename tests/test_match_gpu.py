@@ -830,3 +830,40 @@ def test_keyframe_grid_uses_truncated_origin(oracle, bounds):
         check(fn(0, FrameBounds(*bounds), nt, *[ptr(a) for a in tb], ptr(inv), 8, 5.99, nq, *[ptr(a) for a in qb], ptr(bi),
                  ptr(bd)))
         assert np.array_equal(bi, wbi) and np.array_equal(bd, wbd), kf
+
+
+@pytest.mark.gpu
+def test_knn2_matrix_core_kernel_across_chunks_and_extreme_rows():
+    """The matrix-core kernel folds its running results every 2^21 database rows and starts its
+    accumulators from the rows' set-bit counts: a database of 2^21 + 4999 rows (not a multiple of
+    32) that holds all-zero and all-one rows, duplicates on both sides of the chunk boundary and
+    queries that are all zero / all one, against the popcount kernel."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from orb_slam2_amd import _lib
+    rng = np.random.default_rng(77)
+    ndb, nq = (1 << 21) + 4999, 777
+    db = rng.integers(0, 256, (ndb, 32), dtype=np.uint8)
+    db[5] = 0; db[6] = 255; db[(1 << 21) + 3] = 0; db[(1 << 21) + 4] = 255
+    db[(1 << 21) + 100] = db[100]           # the same row in both chunks: the lower index wins
+    db[ndb - 1] = db[200]
+    q = db[rng.integers(0, ndb, nq)].copy()
+    q[0] = 0; q[1] = 255; q[2] = db[100]; q[3] = db[200]; q[4] = db[(1 << 21) + 7]
+    q[5::9] = rng.integers(0, 256, (len(q[5::9]), 32), dtype=np.uint8)
+    d_q, d_db = torch.from_numpy(q).cuda(), torch.from_numpy(db).cuda()
+    outs = []
+    for algo in (1, 2):
+        res = torch.full((3, nq), -7, dtype=torch.int32, device="cuda")
+        acc = torch.zeros(nq, dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().orb_knn2_device_algo(0, C.c_void_p(d_q.data_ptr()), nq, C.c_void_p(d_db.data_ptr()), ndb, 0, 0.7,
+                                                   C.c_void_p(res[0].data_ptr()), C.c_void_p(res[1].data_ptr()),
+                                                   C.c_void_p(res[2].data_ptr()), C.c_void_p(acc.data_ptr()), None, algo))
+        torch.cuda.synchronize()
+        outs.append((res.cpu().numpy(), acc.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    best, second, idx = outs[1][0]
+    assert best[0] == 0 and idx[0] == 5 and second[0] == 0         # all-zero query: rows 5 and 2^21 + 3
+    assert best[1] == 0 and idx[1] == 6 and second[1] == 0
+    assert best[2] == 0 and idx[2] == 100 and second[2] == 0       # duplicate across the chunk boundary
+    assert best[3] == 0 and idx[3] == 200 and second[3] == 0
+    assert best[4] == 0 and idx[4] == (1 << 21) + 7
