@@ -62,7 +62,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
                                                            float ratio, int* __restrict__ out_best,
                                                            int* __restrict__ out_second, int* __restrict__ out_idx,
                                                            uint8_t* __restrict__ out_accept) {
-  __shared__ uint4 s_db[2 * KNN_TILE + 2];  // + one row read ahead by the software pipeline
+  __shared__ uint4 s_db[2 * KNN_TILE + 4];  // + two rows read ahead by the software pipeline
   const int tid = threadIdx.x;
   const int q0 = (blockIdx.x * KNN_THREADS + tid) * KNN_KQ;
   uint32_t qr[KNN_KQ][8];
@@ -87,11 +87,8 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
       __syncthreads();
       for (int i = tid; i < 2 * tn; i += KNN_THREADS) s_db[i] = db[2 * (size_t)(cbase + t0) + i];
       __syncthreads();
-      uint4 n0 = s_db[0], n1 = s_db[1];
-      for (int j = 0; j < tn; j++) {
-        const uint4 b0 = n0, b1 = n1;
-        n0 = s_db[2 * j + 2]; n1 = s_db[2 * j + 3];  // next row, in flight while this one is scored
-        const uint32_t row = (uint32_t)(t0 + j);
+      // one row against the thread's queries
+      auto score = [&](const uint4& b0, const uint4& b1, const uint32_t row) {
         const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         uint32_t dk[KNN_KQ];
         bool need = false;
@@ -122,6 +119,15 @@ __global__ __launch_bounds__(KNN_THREADS) void knn2_kernel(const uint4* __restri
             s2d[k] = k2[k] >> KNN_ROWBITS;
           }
         }
+      };
+      // Two rows per step, each read into its own registers one row ahead (a single set of
+      // registers that is handed on costs nine moves per row).
+      uint4 n0 = s_db[0], n1 = s_db[1], m0, m1;
+      for (int j = 0; j < tn; j += 2) {
+        m0 = s_db[2 * j + 2]; m1 = s_db[2 * j + 3];
+        score(n0, n1, (uint32_t)(t0 + j));
+        n0 = s_db[2 * j + 4]; n1 = s_db[2 * j + 5];
+        if (j + 1 < tn) score(m0, m1, (uint32_t)(t0 + j + 1));
       }
     }
     // fold the chunk into the running (best, second, index): an earlier chunk keeps ties
