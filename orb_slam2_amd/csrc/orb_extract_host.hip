@@ -1046,7 +1046,11 @@ static int copy_level(OrbExtractor* h, const uint8_t* buf, int frame, int level,
   ORB_HIP_CHECK(hipDeviceSynchronize());
   const uint8_t* src = buf + (size_t)frame * h->plan.slab + L.off +
                        (padded ? (size_t)(kXOff - kEdge) : (size_t)kEdge * L.pitch + kXOff);
-  ORB_HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.pitch, w, hh, hipMemcpyDeviceToHost));
+  // one plain copy of the rows as they lie in the slab, then row by row into the caller's array
+  // (a strided copy straight into pageable memory came back incomplete when a profiler was attached)
+  std::vector<uint8_t> rows((size_t)(hh - 1) * L.pitch + w);
+  ORB_HIP_CHECK(hipMemcpy(rows.data(), src, rows.size(), hipMemcpyDeviceToHost));
+  for (int r = 0; r < hh; r++) memcpy(dst + (size_t)r * dst_stride, rows.data() + (size_t)r * L.pitch, (size_t)w);
   return ORBHIP_OK;
 }
 

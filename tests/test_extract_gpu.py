@@ -64,16 +64,18 @@ def test_extract_matches_oracle(oracle, rows, cols, nf, seed):
     check_stages(ex, ref, nlevels)
 
 
-def test_extract_4k_frame(oracle):
-    """One 3840x2160 frame at 4000 features (BASELINE config 3 shape)."""
+@pytest.mark.parametrize("nf", [4000, 9000])
+def test_extract_4k_frame(oracle, nf):
+    """One 3840x2160 frame at 4000 features (BASELINE config 3 shape), and at 9000: the quad-tree
+    then works with its larger node table on levels that hold tens of thousands of candidates."""
     from orb_slam2_amd import ORBextractor
     from orb_slam2_amd.synth import synth_image
     img = synth_image(2160, 3840, 7, n_shapes=20000)
-    ex = ORBextractor(4000, 1.2, 8, 20, 7)
-    ref = oracle.Extractor(4000, 1.2, 8, 20, 7)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7)
+    ref = oracle.Extractor(nf, 1.2, 8, 20, 7)
     kps, desc = ex(img)
     rk, rd = ref(img)
-    assert len(rk) >= 4000
+    assert len(rk) >= nf
     check_against(kps, desc, rk, rd)
     for l in (0, 3, 7):
         assert np.array_equal(ex.fast_candidates(l), ref.candidates(l))
@@ -374,8 +376,11 @@ def test_blur_fused_into_descriptors(oracle, compat):
         for f in (0, 4, 6):
             k1, d1 = a(seq[f])
             assert np.array_equal(k1, bk[f]) and np.array_equal(d1, bd[f]), (rows, f)
+            k2, d2 = b(seq[f])  # single frame with the levels blurred to memory
+            assert np.array_equal(k2, bk[f]) and np.array_equal(d2, bd[f]), (rows, f)
         # the blurred level is made on demand after a fused call and equals the one written up front
         a.extract_batch(seq)
+        b.extract_batch(seq)
         for l in (0, nlev - 1):
             assert np.array_equal(a.blurred_level(l, 7), b.blurred_level(l, 7))
 
@@ -442,6 +447,30 @@ def test_batch_stages_match_oracle(oracle, rows, cols, nlevels, scale):
     ref = oracle.Extractor(1000, scale, nlevels, 20, 7)
     for f in (0, 6, 10):
         rk, rd = ref(seq[f])
+        check_against(bk[f], bd[f], rk, rd)
+        check_stages(ex, ref, nlevels, frame=f)
+
+
+@pytest.mark.parametrize("n", [1, 9])
+def test_wide_level_at_a_large_scale_factor_takes_the_generic_resize(oracle, n):
+    """Scale factor 1.6 on an 1800-px-wide image: a 1024-column tile of level 1 would need more
+    source columns than the tiled resize kernel stages, so that level is made by the generic
+    kernel (a thread per four output pixels, taps from the tables) while the narrower levels above
+    it stay tiled; one frame (host call) and a batch, every stage against the oracle."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd.synth import synth_sequence
+    rows, cols, nlevels, scale = 300, 1800, 4, 1.6
+    seq = synth_sequence(rows, cols, n, seed=31, step=3)
+    ex = ORBextractor(1200, scale, nlevels, 20, 7)
+    ref = oracle.Extractor(1200, scale, nlevels, 20, 7)
+    if n == 1:
+        kps, desc = ex(seq[0])
+        bk, bd = [kps], [desc]
+    else:
+        bk, bd = ex.extract_batch(seq)
+    for f in sorted({0, n - 1}):
+        rk, rd = ref(seq[f])
+        assert len(rk) > 300
         check_against(bk[f], bd[f], rk, rd)
         check_stages(ex, ref, nlevels, frame=f)
 
