@@ -1443,6 +1443,13 @@ constexpr int D_WAVE_BYTES = D_PAD + (D_RAW_ROWS + D_BLR_ROWS) * D_PITCH;
 //                      4 dwords of |u| (0 outside the disc) and 4 dwords of 0/1.
 __device__ float4 d_patf[256];
 __device__ uint32_t d_odw[32][2][8];
+//  d_hitems[a][i]    = item i of the fused blur's row pass (three rounds of 64 lanes) for a patch whose first
+//                      column lies a bytes into its dword: the staged byte offset of the item's dwords (pair of
+//                      rows, group of four columns; + 4, so that it is not negative) and, in the upper half, the
+//                      byte offset of its results.  Only the items that a sampled pixel can depend on are listed:
+//                      the rotated pattern stays in a disc, and the corners of the 37 x 37 patch are never read.
+constexpr int DF_ITEMS = 192;
+__device__ uint32_t d_hitems[4][DF_ITEMS];
 
 // cos and sin of x in [0, 2*pi + small]: quadrant reduction and the classic double precision
 // minimax kernels on [-pi/4, pi/4] (error about 1e-16, so rounding the result to float gives
@@ -1552,19 +1559,14 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
   uint8_t* s_raw = s_patch[threadIdx.x >> 6] + D_PAD;
   uint8_t* s_blr = s_raw + D_RAW_ROWS * D_PITCH;                                        // MODE 0
   uint8_t* s_hp = s_raw + DF_RAW_ROWS * DF_PITCH;                                       // fused: row-pass results
-  // fused form, row pass: item = (pair of staged rows 0..21, group of 4 columns 0..9), 220 items in
-  // 4 rounds of 64 lanes; column pass: lane = (group of 4 columns 0..9, strip 0..5 of the 7 rows
-  // from row 6 * strip on: a strip starts on an even row, its last row is the next one's first)
-  int h_src[4], h_dst[4], v_src = 0, v_dst = 0;
+  // fused form, row pass: item = (pair of staged rows 0..21, group of 4 columns 0..9); of the 220
+  // items the 192 (or fewer) listed in d_hitems, in 3 rounds of 64 lanes; column pass: lane =
+  // (group of 4 columns 0..9, strip 0..5 of the 7 rows from row 6 * strip on: a strip starts on an
+  // even row, its last row is the next one's first)
+  int v_src = 0, v_dst = 0;
   uint32_t HA0 = 0, HB0 = 0, HA1 = 0, HB1 = 0, HC1 = 0, HA2 = 0, HB2 = 0, HC2 = 0, HC3 = 0;
   uint32_t T1 = 0, TPe0 = 0, TPe1 = 0, TPe2 = 0, TPe3 = 0, TPo0 = 0, TPo1 = 0, TPo2 = 0, TPo3 = 0;
   if constexpr (FUSED) {
-#pragma unroll
-    for (int rd = 0; rd < 4; rd++) {
-      const int item = lane + 64 * rd, pr = (item * 6554) >> 16, g = item - 10 * pr;  // item / 10 for item < 256
-      h_src[rd] = 2 * pr * DF_PITCH + 4 * (g - 1);
-      h_dst[rd] = pr * (DF_HP_PITCH * 4) + 16 * g;
-    }
     const int vs = (lane * 6554) >> 16, vq = lane - 10 * vs;
     v_src = 3 * vs * (DF_HP_PITCH * 4) + 16 * vq;
     v_dst = 6 * vs * DF_B_PITCH + 4 * vq;
@@ -1667,6 +1669,15 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
     if constexpr (FUSED) return od_issue_fused(fpyr, q.lvl, q.cx, q.pitch, rs, seg);
     else return od_issue(fpyr, fblur, q.lvl, q.cx, q.pitch, rs, seg);
   };
+  // this lane's row-pass items of the fused blur (see d_hitems): requested along with a keypoint's
+  // patch, one keypoint ahead
+  uint32_t hit[3] = {0, 0, 0};
+  auto issue_items = [&](const Loc& q) {
+    if constexpr (FUSED) {
+      const uint32_t* tab = &d_hitems[(q.cx + kXOff - 21 + 3) & 3][lane];
+      hit[0] = tab[0]; hit[1] = tab[64]; hit[2] = tab[128];
+    }
+  };
   Loc cur;
   float ang_v = 0.f, cos_v = 1.f, sin_v = 0.f;
   {
@@ -1688,7 +1699,7 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
       c1[kk] = *reinterpret_cast<const uint32_t*>(g + 16);
       if (kk == 0) {  // the first keypoint's patches are on their way while the moments are summed
         cur = q;
-        if (q.ok) st = issue(q);
+        if (q.ok) { st = issue(q); issue_items(q); }
       }
     }
     int m10_v = 0, m01_v = 0;
@@ -1777,12 +1788,13 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
   for (int kk = 0; kk < KPW; kk++) {
   const Loc nxt = locate(kk + 1);
   if (!cur.ok) {
-    if (nxt.ok) st = issue(nxt);
+    if (nxt.ok) { st = issue(nxt); issue_items(nxt); }
     cur = nxt;
     continue;
   }
   const int o = cur.o, cx = cur.cx;
   const int al = (cx + kXOff - (FUSED ? 21 : 15)) & 15, al2 = (cx + kXOff - 18) & 15;
+  const uint32_t hit0 = hit[0], hit1 = hit[1], hit2 = hit[2];  // (hit[] goes on to the next keypoint's)
   if constexpr (FUSED) {
     uint32_t* dr = reinterpret_cast<uint32_t*>(&s_raw[rs * DF_PITCH + 16 * seg]);
     auto put = [&](int rows, const uint4& v) {
@@ -1796,7 +1808,7 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
     dr[0] = st.a0; dr[16 * (D_PITCH / 16)] = st.a1;
     db[0] = st.b0; db[16 * (D_PITCH / 16)] = st.b1; db[32 * (D_PITCH / 16)] = st.b2;
   }
-  if (nxt.ok) st = issue(nxt);
+  if (nxt.ok) { st = issue(nxt); issue_items(nxt); }
   od_wave_sync();
 
   const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cos_v), kk));
@@ -1809,11 +1821,11 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
     // first column (-18) is staged byte al + 3.  Pixel j of a group uses bytes j + 1 .. j + 7 of
     // the three dwords from the one before the group on; the results of two rows share a dword.
     const int G0 = (al + 3) >> 2;
-    uint32_t wr[4][2][3];  // every round's dwords are read before the first results are stored
+    uint32_t wr[3][2][3];  // every round's dwords are read before the first results are stored
 #pragma unroll
-    for (int rd = 0; rd < 4; rd++) {
-      // (the last round's idle lanes read what item 219 reads)
-      const uint8_t* src = s_raw + (rd < 3 || lane < 220 - 192 ? h_src[rd] : 2 * 21 * DF_PITCH + 4 * 8) + 4 * G0;
+    for (int rd = 0; rd < 3; rd++) {
+      const uint32_t hv = rd == 0 ? hit0 : rd == 1 ? hit1 : hit2;
+      const uint8_t* src = s_raw + (hv & 0xFFFFu) + (4 * G0 - 4);
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(src + k * DF_PITCH);
@@ -1821,8 +1833,8 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
       }
     }
 #pragma unroll
-    for (int rd = 0; rd < 4; rd++) {
-      if (rd < 3 || lane < 220 - 192) {
+    for (int rd = 0; rd < 3; rd++) {
+      {
         uint32_t hh[2][4];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -1837,7 +1849,7 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
         // (results are below 2^16: the low halves of the two rows' sums make the dword)
         o.x = __builtin_amdgcn_perm(hh[1][0], hh[0][0], 0x05040100u); o.y = __builtin_amdgcn_perm(hh[1][1], hh[0][1], 0x05040100u);
         o.z = __builtin_amdgcn_perm(hh[1][2], hh[0][2], 0x05040100u); o.w = __builtin_amdgcn_perm(hh[1][3], hh[0][3], 0x05040100u);
-        *reinterpret_cast<uint4*>(s_hp + h_dst[rd]) = o;
+        *reinterpret_cast<uint4*>(s_hp + ((rd == 0 ? hit0 : rd == 1 ? hit1 : hit2) >> 16)) = o;
       }
     }
     od_wave_sync();
@@ -1920,7 +1932,37 @@ hipError_t upload_orient_tables() {
         wt[(row * 2 + half) * 8 + 4 + bt / 4] |= 1u << (8 * (bt & 3));
       }
   }
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(d_patf), pf.data(), sizeof(float4) * 256);
+  // Row-pass items of the fused blur.  A sampled pixel is (round(x b + y a), round(x a - y b)) for a
+  // pattern point (x, y), |x|, |y| <= 13, and a rotation (a, b): it lies within half a pixel, per
+  // coordinate, of a point of the disc of radius 13 sqrt(2) (+ a margin for the float arithmetic).
+  // The blurred pixel at (r, q) needs the row pass at rows r - 3 .. r + 3, column q.  Item (pr, g)
+  // holds staged rows -21 + 2 pr and the next one, columns 4 g - a - 18 .. + 3.
+  std::vector<uint32_t> hit(4 * DF_ITEMS);
+  for (int a = 0; a < 4; a++) {
+    int n = 0;
+    uint32_t last = 0;
+    for (int pr = 0; pr < 22; pr++)
+      for (int g = 0; g < 10; g++) {
+        bool need = false;
+        for (int sr = -21 + 2 * pr; sr <= -20 + 2 * pr; sr++)
+          for (int j = 0; j < 4; j++) {
+            const int q = 4 * g + j - a - 18;
+            for (int r = std::max(sr - 3, -18); r <= std::min(sr + 3, 18); r++) {
+              const double dr = std::max(std::abs(r) - 0.5, 0.0), dq = std::max(std::abs(q) - 0.5, 0.0);
+              if (dr * dr + dq * dq <= 338.5) need = true;
+            }
+          }
+        if (!need) continue;
+        if (n >= DF_ITEMS) return hipErrorInvalidValue;  // (cannot happen: 189 or 190 items)
+        last = (uint32_t)(2 * pr * DF_PITCH + 4 * g) | ((uint32_t)(pr * (DF_HP_PITCH * 4) + 16 * g) << 16);
+        hit[a * DF_ITEMS + n++] = last;
+      }
+    if (n == 0) return hipErrorInvalidValue;
+    for (; n < DF_ITEMS; n++) hit[a * DF_ITEMS + n] = last;  // idle lanes repeat the last item
+  }
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(d_hitems), hit.data(), sizeof(uint32_t) * hit.size());
+  if (e != hipSuccess) return e;
+  e = hipMemcpyToSymbol(HIP_SYMBOL(d_patf), pf.data(), sizeof(float4) * 256);
   if (e != hipSuccess) return e;
   return hipMemcpyToSymbol(HIP_SYMBOL(d_odw), wt.data(), sizeof(uint32_t) * wt.size());
 }
