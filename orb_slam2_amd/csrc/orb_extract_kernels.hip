@@ -1450,6 +1450,9 @@ __device__ uint32_t d_odw[32][2][8];
 //                      the rotated pattern stays in a disc, and the corners of the 37 x 37 patch are never read.
 constexpr int DF_ITEMS = 192;
 __device__ uint32_t d_hitems[4][DF_ITEMS];
+//  d_vitems[a][lane] = the same for the column pass: a lane's block of 6 rows x 4 columns of the blurred patch (byte
+//                      offset of the first of the six row pairs it reads; byte offset of its first output).
+__device__ uint32_t d_vitems[4][64];
 
 // cos and sin of x in [0, 2*pi + small]: quadrant reduction and the classic double precision
 // minimax kernels on [-pi/4, pi/4] (error about 1e-16, so rounding the result to float gives
@@ -1563,13 +1566,9 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
   // items the 192 (or fewer) listed in d_hitems, in 3 rounds of 64 lanes; column pass: lane =
   // (group of 4 columns 0..9, strip 0..5 of the 7 rows from row 6 * strip on: a strip starts on an
   // even row, its last row is the next one's first)
-  int v_src = 0, v_dst = 0;
   uint32_t HA0 = 0, HB0 = 0, HA1 = 0, HB1 = 0, HC1 = 0, HA2 = 0, HB2 = 0, HC2 = 0, HC3 = 0;
   uint32_t T1 = 0, TPe0 = 0, TPe1 = 0, TPe2 = 0, TPe3 = 0, TPo0 = 0, TPo1 = 0, TPo2 = 0, TPo3 = 0;
   if constexpr (FUSED) {
-    const int vs = (lane * 6554) >> 16, vq = lane - 10 * vs;
-    v_src = 3 * vs * (DF_HP_PITCH * 4) + 16 * vq;
-    v_dst = 6 * vs * DF_B_PITCH + 4 * vq;
     // Row pass: pixel j of a group of 4 uses bytes j + 1 .. j + 7 of three dwords; instead of
     // shifting the bytes into place, each pixel has its own copies of the taps (t0 t1 t2 t3 t2 t1
     // t0), shifted: HA* go with the first dword, HB* / T1 with the second, HC* with the third.
@@ -1671,11 +1670,13 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
   };
   // this lane's row-pass items of the fused blur (see d_hitems): requested along with a keypoint's
   // patch, one keypoint ahead
-  uint32_t hit[3] = {0, 0, 0};
+  uint32_t hit[4] = {0, 0, 0, 0};
   auto issue_items = [&](const Loc& q) {
     if constexpr (FUSED) {
-      const uint32_t* tab = &d_hitems[(q.cx + kXOff - 21 + 3) & 3][lane];
+      const int a = (q.cx + kXOff - 21 + 3) & 3;
+      const uint32_t* tab = &d_hitems[a][lane];
       hit[0] = tab[0]; hit[1] = tab[64]; hit[2] = tab[128];
+      hit[3] = d_vitems[a][lane];
     }
   };
   Loc cur;
@@ -1794,7 +1795,7 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
   }
   const int o = cur.o, cx = cur.cx;
   const int al = (cx + kXOff - (FUSED ? 21 : 15)) & 15, al2 = (cx + kXOff - 18) & 15;
-  const uint32_t hit0 = hit[0], hit1 = hit[1], hit2 = hit[2];  // (hit[] goes on to the next keypoint's)
+  const uint32_t hit0 = hit[0], hit1 = hit[1], hit2 = hit[2], hit3 = hit[3];  // (hit[] goes on to the next keypoint's)
   if constexpr (FUSED) {
     uint32_t* dr = reinterpret_cast<uint32_t*>(&s_raw[rs * DF_PITCH + 16 * seg]);
     auto put = [&](int rows, const uint4& v) {
@@ -1853,15 +1854,17 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
       }
     }
     od_wave_sync();
-    // Column pass: 7 output rows x 4 columns per lane from 7 pairs of rows; output row i (patch
-    // row i - 18) uses staged rows i .. i + 6.  The blurred patch overwrites the staged level.
-    if (lane < 60) {
-      const uint4* hp = reinterpret_cast<const uint4*>(s_hp + v_src);
-      uint4 v[7];
+    // Column pass: 6 output rows x 4 columns per lane from 6 pairs of rows (the lane's block: see
+    // d_vitems); output row i (patch row i - 18) uses staged rows i .. i + 6.  The blurred patch
+    // overwrites the staged level.
+    {
+      const uint4* hp = reinterpret_cast<const uint4*>(s_hp + (hit3 & 0xFFFFu));
+      const uint32_t v_dst = hit3 >> 16;
+      uint4 v[6];
 #pragma unroll
-      for (int k = 0; k < 7; k++) v[k] = hp[k * (DF_HP_PITCH / 4)];
+      for (int k = 0; k < 6; k++) v[k] = hp[k * (DF_HP_PITCH / 4)];
 #pragma unroll
-      for (int j = 0; j < 7; j++) {
+      for (int j = 0; j < 6; j++) {
         const int p = j >> 1;
         const uint32_t tp0 = (j & 1) ? TPo0 : TPe0, tp1 = (j & 1) ? TPo1 : TPe1, tp2 = (j & 1) ? TPo2 : TPe2, tp3 = (j & 1) ? TPo3 : TPe3;
         uint32_t c0 = blur_dot2(v[p + 3].x, tp3, blur_dot2(v[p + 2].x, tp2, blur_dot2(v[p + 1].x, tp1, blur_dot2(v[p].x, tp0, 32768u))));
@@ -1960,7 +1963,33 @@ hipError_t upload_orient_tables() {
     if (n == 0) return hipErrorInvalidValue;
     for (; n < DF_ITEMS; n++) hit[a * DF_ITEMS + n] = last;  // idle lanes repeat the last item
   }
+  // Column-pass blocks: strips of six output rows from patch row -18 on (the seventh strip would hold row 18
+  // alone: it is rows 14 .. 19 instead, which start on an even staged row like the others and need no row
+  // pair beyond those the row pass makes; rows 14 .. 17 are then written twice, with the same values)
+  std::vector<uint32_t> vit(4 * 64);
+  for (int a = 0; a < 4; a++) {
+    int n = 0;
+    uint32_t last = 0;
+    for (int st = 0; st < 7; st++)
+      for (int g = 0; g < 10; g++) {
+        const int r0 = st < 6 ? -18 + 6 * st : 14;
+        bool need = false;
+        for (int r = st < 6 ? r0 : 18; r <= std::min(r0 + 5, 18); r++)
+          for (int j = 0; j < 4; j++) {
+            const int q = 4 * g + j - a - 18;
+            const double dr = std::max(std::abs(r) - 0.5, 0.0), dq = std::max(std::abs(q) - 0.5, 0.0);
+            if (dr * dr + dq * dq <= 338.5) need = true;
+          }
+        if (!need) continue;
+        if (n >= 64) return hipErrorInvalidValue;  // (cannot happen: 59 or 60 blocks)
+        last = (uint32_t)((r0 + 18) / 2 * (DF_HP_PITCH * 4) + 16 * g) | ((uint32_t)((r0 + 18) * DF_B_PITCH + 4 * g) << 16);
+        vit[a * 64 + n++] = last;
+      }
+    for (; n < 64; n++) vit[a * 64 + n] = last;
+  }
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(d_hitems), hit.data(), sizeof(uint32_t) * hit.size());
+  if (e != hipSuccess) return e;
+  e = hipMemcpyToSymbol(HIP_SYMBOL(d_vitems), vit.data(), sizeof(uint32_t) * vit.size());
   if (e != hipSuccess) return e;
   e = hipMemcpyToSymbol(HIP_SYMBOL(d_patf), pf.data(), sizeof(float4) * 256);
   if (e != hipSuccess) return e;
