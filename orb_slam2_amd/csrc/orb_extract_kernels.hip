@@ -1664,9 +1664,12 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
   // below then finds a keypoint's angle and rotation in lane j of these registers.
   const int rs = lane >> 2, seg = lane & 3;
   Staged st;
+  // (an empty slot - pitch 0, column 0 - reads near the start of the slab, and its pieces are not used: the loads
+  // are issued without a branch, so that the registers they fill are not handed on through copies)
   auto issue = [&](const Loc& q) {
-    if constexpr (FUSED) return od_issue_fused(fpyr, q.lvl, q.cx, q.pitch, rs, seg);
-    else return od_issue(fpyr, fblur, q.lvl, q.cx, q.pitch, rs, seg);
+    const uint32_t lvl = q.ok ? q.lvl : 64u;
+    if constexpr (FUSED) return od_issue_fused(fpyr, lvl, q.cx, q.pitch, rs, seg);
+    else return od_issue(fpyr, fblur, lvl, q.cx, q.pitch, rs, seg);
   };
   // this lane's row-pass items of the fused blur (see d_hitems): requested along with a keypoint's
   // patch, one keypoint ahead
@@ -1700,7 +1703,8 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
       c1[kk] = *reinterpret_cast<const uint32_t*>(g + 16);
       if (kk == 0) {  // the first keypoint's patches are on their way while the moments are summed
         cur = q;
-        if (q.ok) { st = issue(q); issue_items(q); }
+        st = issue(q);
+        issue_items(q);
       }
     }
     int m10_v = 0, m01_v = 0;
@@ -1788,28 +1792,32 @@ __global__ __launch_bounds__(THREADS) void orient_desc_kernel(const uint8_t* __r
 #pragma unroll
   for (int kk = 0; kk < KPW; kk++) {
   const Loc nxt = locate(kk + 1);
-  if (!cur.ok) {
-    if (nxt.ok) { st = issue(nxt); issue_items(nxt); }
-    cur = nxt;
-    continue;
-  }
   const int o = cur.o, cx = cur.cx;
   const int al = (cx + kXOff - (FUSED ? 21 : 15)) & 15, al2 = (cx + kXOff - 18) & 15;
   const uint32_t hit0 = hit[0], hit1 = hit[1], hit2 = hit[2], hit3 = hit[3];  // (hit[] goes on to the next keypoint's)
-  if constexpr (FUSED) {
-    uint32_t* dr = reinterpret_cast<uint32_t*>(&s_raw[rs * DF_PITCH + 16 * seg]);
-    auto put = [&](int rows, const uint4& v) {
-      uint32_t* d = dr + rows * (DF_PITCH / 4);
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    };
-    put(0, st.a0); put(16, st.a1); put(32, st.b0);
-  } else {
-    uint4* dr = reinterpret_cast<uint4*>(&s_raw[rs * D_PITCH + 16 * seg]);
-    uint4* db = reinterpret_cast<uint4*>(&s_blr[rs * D_PITCH + 16 * seg]);
-    dr[0] = st.a0; dr[16 * (D_PITCH / 16)] = st.a1;
-    db[0] = st.b0; db[16 * (D_PITCH / 16)] = st.b1; db[32 * (D_PITCH / 16)] = st.b2;
+  if (cur.ok) {
+    if constexpr (FUSED) {
+      uint32_t* dr = reinterpret_cast<uint32_t*>(&s_raw[rs * DF_PITCH + 16 * seg]);
+      auto put = [&](int rows, const uint4& v) {
+        uint32_t* d = dr + rows * (DF_PITCH / 4);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      };
+      put(0, st.a0); put(16, st.a1); put(32, st.b0);
+    } else {
+      uint4* dr = reinterpret_cast<uint4*>(&s_raw[rs * D_PITCH + 16 * seg]);
+      uint4* db = reinterpret_cast<uint4*>(&s_blr[rs * D_PITCH + 16 * seg]);
+      dr[0] = st.a0; dr[16 * (D_PITCH / 16)] = st.a1;
+      db[0] = st.b0; db[16 * (D_PITCH / 16)] = st.b1; db[32 * (D_PITCH / 16)] = st.b2;
+    }
   }
-  if (nxt.ok) { st = issue(nxt); issue_items(nxt); }
+  if (kk + 1 < KPW) {  // (known at compile time: the loop is unrolled)
+    st = issue(nxt);
+    issue_items(nxt);
+  }
+  if (!cur.ok) {
+    cur = nxt;
+    continue;
+  }
   od_wave_sync();
 
   const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cos_v), kk));
