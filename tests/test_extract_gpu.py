@@ -1,6 +1,6 @@
 """GPU parity of the extractor against the CPU oracle and the golden vectors.
 
-Bars (BASELINE north star): pyramid pixels, keypoint x / y / octave and FAST responses
+Bars: pyramid pixels, keypoint x / y / octave and FAST responses
 bit-exact; angles within 1e-4 rad; at least 99.9 % of descriptors bit-identical.
 """
 import os
@@ -39,7 +39,7 @@ def check_stages(ex, ref, nlevels, frame=0):
 
 
 @pytest.mark.parametrize("rows,cols,nf,seed", [
-    (480, 640, 1000, 0),      # TUM shape, BASELINE config 0
+    (480, 640, 1000, 0),      # TUM shape, benchmark configuration 0
     (376, 1241, 2000, 0),     # KITTI shape, config 1
     (480, 752, 1200, 0),      # EuRoC left eye, config 2
     (480, 752, 1200, 1),      # EuRoC right eye
@@ -66,7 +66,7 @@ def test_extract_matches_oracle(oracle, rows, cols, nf, seed):
 
 @pytest.mark.parametrize("nf", [4000, 9000])
 def test_extract_4k_frame(oracle, nf):
-    """One 3840x2160 frame at 4000 features (BASELINE config 3 shape), and at 9000: the quad-tree
+    """One 3840x2160 frame at 4000 features (benchmark configuration 3 shape), and at 9000: the quad-tree
     then works with its larger node table on levels that hold tens of thousands of candidates."""
     from orb_slam2_amd import ORBextractor
     from orb_slam2_amd.synth import synth_image

@@ -22,9 +22,9 @@ from orb_slam2_amd.synth import synth_descriptors, synth_image  # noqa: E402
 CASES = {
     # name: (rows, cols, seed, nfeatures, nlevels)
     "small_240x320": (240, 320, 5, 500, 8),
-    "tum_480x640": (480, 640, 0, 1000, 8),       # BASELINE config 0
-    "kitti_376x1241": (376, 1241, 0, 2000, 8),   # BASELINE config 1
-    "euroc_480x752": (480, 752, 0, 1200, 8),     # BASELINE config 2 (one eye)
+    "tum_480x640": (480, 640, 0, 1000, 8),       # benchmark configuration 0
+    "kitti_376x1241": (376, 1241, 0, 2000, 8),   # benchmark configuration 1
+    "euroc_480x752": (480, 752, 0, 1200, 8),     # benchmark configuration 2 (one eye)
 }
 
 
