@@ -6,7 +6,8 @@ src=gpurun_out/prof_$tag
 python3 - "$tag" "$src" <<'PY'
 import csv, glob, sys
 tag, src = sys.argv[1], sys.argv[2]
-fn = glob.glob(src + '/stats/*/*kernel_stats.csv')[0]
+import os
+fn = max(glob.glob(src + '/stats/*/*kernel_stats.csv'), key=os.path.getmtime)  # (earlier runs' files may still lie there)
 rows = [r for r in csv.reader(open(fn))]
 out = open('profiles/%s_kernel_stats.csv' % tag, 'w')
 out.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-frames 0 --host-reps 0 --knn-reps 3 "
