@@ -475,6 +475,42 @@ def test_wide_level_at_a_large_scale_factor_takes_the_generic_resize(oracle, n):
         check_stages(ex, ref, nlevels, frame=f)
 
 
+def test_level_read_back_into_a_strided_array(oracle):
+    """orb_get_pyramid_level / orb_get_blurred_level write rows of the level's width into an array whose
+    rows are longer (a cv::Mat with a step, as mvImagePyramid may be): the level lands in the left part
+    of every row, the bytes to the right stay as they were, padded and unpadded, several frames."""
+    import ctypes as C
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd._lib import check, lib, ptr
+    from orb_slam2_amd.synth import synth_sequence
+    seq = synth_sequence(211, 333, 3, seed=9, step=2)
+    ex = ORBextractor(500, 1.2, 4, 20, 7)
+    ex.extract_batch(seq)
+    ref = oracle.Extractor(500, 1.2, 4, 20, 7)
+    ref(seq[2])
+    L = lib()
+    for level in (0, 3):
+        for padded in (0, 1):
+            w, h = C.c_int(), C.c_int()
+            check(L.orb_get_pyramid_level(ex._h, 2, level, padded, None, 0, C.byref(w), C.byref(h)))
+            stride = w.value + 37
+            out = np.full((h.value, stride), 0xA5, np.uint8)
+            check(L.orb_get_pyramid_level(ex._h, 2, level, padded, ptr(out), stride, None, None))
+            want = ref.pyramid_level(level)
+            if not padded:
+                want = want[19:-19, 19:-19]
+            assert np.array_equal(out[:, :w.value], want), (level, padded)
+            assert np.all(out[:, w.value:] == 0xA5), (level, padded)
+        w, h = C.c_int(), C.c_int()
+        check(L.orb_get_blurred_level(ex._h, 2, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.full((h.value, w.value + 5), 0x5A, np.uint8)
+        check(L.orb_get_blurred_level(ex._h, 2, level, ptr(out), w.value + 5, None, None))
+        assert np.array_equal(out[:, :w.value], ex.blurred_level(level, 2)), level
+        assert np.all(out[:, w.value:] == 0x5A), level
+    # a destination narrower than the level is refused
+    assert L.orb_get_pyramid_level(ex._h, 0, 0, 0, ptr(out), 10, None, None) < 0
+
+
 def _colour_image(rows, cols, ch, seed):
     """A colour image whose grey value has corners: the synthetic grey scene modulated per
     channel, plus noise, so that the three weights all matter."""
