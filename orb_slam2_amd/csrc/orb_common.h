@@ -58,6 +58,21 @@ struct YTab {  // vertical taps of one destination row
 struct FastItem {  // a run of cells in one cell row, handled by one workgroup
   int16_t level, row, j0, ncells;
 };
+// What the FAST kernel needs to know about an item, worked out on the host: a workgroup fetches
+// this one record and nothing of the plan's level table (whose entry it could only ask for after
+// the item had arrived: one memory round trip less at the start of every workgroup).
+struct FastWork {
+  int32_t base_off;            // byte offset, in a frame's slab, of the staged view's first dword
+  int32_t pitch;               // slab row pitch of the level
+  int32_t cand_off, cand_cap;  // the level's slice of the frame's candidate array
+  int32_t wCellM;              // 65536 / wCell + 1
+  int16_t level, ncells, wCell, hCell;
+  int16_t tw, th;              // size of the view (cells' pixels + 6), clipped to the level
+  int16_t xb, iniY;            // its origin in level coordinates
+  int16_t xoff, ndw;           // LDS column of the first interior pixel; dwords staged per row
+  int16_t pad[4];
+};
+static_assert(sizeof(FastWork) == 48, "three 16-byte words");
 struct BlurItem {
   int16_t level, tx, ty, pad;
 };

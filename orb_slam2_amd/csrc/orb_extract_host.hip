@@ -20,7 +20,7 @@ namespace orbhip {
 void launch_pyr_level0(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, int*, int, hipStream_t);
 void launch_pyr_level0_color(const uint8_t*, size_t, size_t, int, bool, const int*, uint8_t*, const Plan&, int*, int, hipStream_t);
 void launch_pyr_resize(uint8_t*, const Plan&, int, const XTab*, const YTab*, int, hipStream_t);
-void launch_fast(const uint8_t*, const Plan&, const FastItem*, int, int, uint32_t*, int*, int, int, int, hipStream_t);
+void launch_fast(const uint8_t*, const Plan&, const FastWork*, int, int, uint32_t*, int*, int, int, int, hipStream_t);
 int fast_rows_dense();
 int fast_use_width_narrow();
 void launch_pyr_resize_dual(uint8_t*, const Plan&, int, const uint32_t*, const uint32_t*, const YTab*, const int2*, int,
@@ -190,7 +190,7 @@ struct OrbExtractor {
   bool fused_blur = true, blur_stale = false;
   XTab* d_xtab = nullptr;
   YTab* d_ytab = nullptr;
-  FastItem* d_fast_items = nullptr;
+  FastWork* d_fast_items = nullptr;
   BlurItem* d_blur_items = nullptr;
   uint32_t *d_cand = nullptr, *d_pnode = nullptr, *d_sel = nullptr;
   int *d_cand_cnt = nullptr, *d_sel_cnt = nullptr;
@@ -402,11 +402,27 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   ORB_HIP_CHECK(hipMemsetAsync(h->d_blur, 0, P.slab * cap, h->stream));
   ORB_HIP_CHECK(hipMalloc(&h->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1)));
   ORB_HIP_CHECK(hipMalloc(&h->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1)));
-  ORB_HIP_CHECK(hipMalloc(&h->d_fast_items, sizeof(FastItem) * fi.size()));
+  // the items as the kernel reads them (see FastWork; the same arithmetic the kernel used to do per workgroup)
+  std::vector<FastWork> fw(fi.size());
+  for (size_t i = 0; i < fi.size(); i++) {
+    const FastItem& it = fi[i];
+    const LevelGeom& L = P.lv[it.level];
+    FastWork& w = fw[i];
+    memset(&w, 0, sizeof(w));
+    const int iniY = kBorder + it.row * L.hCell, maxY = std::min(iniY + L.hCell + 6, L.maxBY);
+    const int xb = kBorder + it.j0 * L.wCell, xe = std::min(kBorder + (it.j0 + it.ncells) * L.wCell + 6, L.maxBX);
+    const int a0 = (xb + kXOff) & ~3, xoff = (xb + kXOff) - a0 + 3, wi = xe - xb - 6;
+    w.base_off = L.off + (iniY + kEdge) * L.pitch + a0;
+    w.pitch = L.pitch; w.cand_off = L.cand_off; w.cand_cap = L.cand_cap; w.wCellM = L.wCellM;
+    w.level = it.level; w.ncells = it.ncells; w.wCell = (int16_t)L.wCell; w.hCell = (int16_t)L.hCell;
+    w.tw = (int16_t)(xe - xb); w.th = (int16_t)(maxY - iniY); w.xb = (int16_t)xb; w.iniY = (int16_t)iniY;
+    w.xoff = (int16_t)xoff; w.ndw = (int16_t)((xoff + 3 + wi + 3) >> 2);
+  }
+  ORB_HIP_CHECK(hipMalloc(&h->d_fast_items, sizeof(FastWork) * fw.size()));
   ORB_HIP_CHECK(hipMalloc(&h->d_blur_items, sizeof(BlurItem) * bi.size()));
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_xtab, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice, h->stream));
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_ytab, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice, h->stream));
-  ORB_HIP_CHECK(hipMemcpyAsync(h->d_fast_items, fi.data(), sizeof(FastItem) * fi.size(), hipMemcpyHostToDevice, h->stream));
+  ORB_HIP_CHECK(hipMemcpyAsync(h->d_fast_items, fw.data(), sizeof(FastWork) * fw.size(), hipMemcpyHostToDevice, h->stream));
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_blur_items, bi.data(), sizeof(BlurItem) * bi.size(), hipMemcpyHostToDevice, h->stream));
   {
     // tables of the tiled resize kernel

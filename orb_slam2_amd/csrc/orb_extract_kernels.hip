@@ -534,8 +534,9 @@ struct FastShared {
   int* vars;  // total, base, emit of the dense sweep
 };
 
+struct FastPlan { unsigned long long slab; int cand_total, nlevels; };  // what the kernel needs of the plan
 template <int FP>  // LDS row pitch of the staged view and of the V map
-__device__ __forceinline__ void fast_body(const uint8_t* __restrict__ pyr, const Plan& P, const FastItem item,
+__device__ __forceinline__ void fast_body(const uint8_t* __restrict__ pyr, const FastPlan& P, const FastWork& item,
                                           uint32_t* __restrict__ cand_all, int* __restrict__ cand_cnt, int iniTh,
                                           int minTh, int lds_rows, const FastShared S) {
   // staged view and its V map: lds_rows rows each (the tallest cell view of the class)
@@ -554,23 +555,20 @@ __device__ __forceinline__ void fast_body(const uint8_t* __restrict__ pyr, const
   // the wave index as a scalar: loops over "rows of this wave" are then uniform for the compiler,
   // and the queue length and list addresses stay in scalar registers
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const LevelGeom& L = P.lv[item.level];
-  const int wCell = L.wCell, hCell = L.hCell;
-  const int wCellM = L.wCellM;  // div_small(n, wCellM) = n / wCell
-  const int iniY = kBorder + item.row * hCell;
-  const int maxY = min(iniY + hCell + 6, L.maxBY);
-  const int xb = kBorder + item.j0 * wCell;
-  const int xe = min(kBorder + (item.j0 + item.ncells) * wCell + 6, L.maxBX);
-  const int tw = xe - xb, th = maxY - iniY;
+  // (the view's geometry comes worked out with the item: see FastWork)
+  const int wCell = item.wCell;
+  const int wCellM = item.wCellM;  // div_small(n, wCellM) = n / wCell
+  const int iniY = item.iniY, xb = item.xb;
+  const int tw = item.tw, th = item.th;
   const int wi = tw - 6, hi = th - 6;  // interior (pixels that can be corners); wi <= F_USEW
   if (wi <= 0 || hi <= 0) return;      // uniform: a view shorter than 7 rows yields nothing
 
-  // stage the view, dword-aligned on the slab: a wave per row.  LDS column 0 is slab
-  // column a0; interior pixel x sits in LDS column x + xoff.
-  const int a0 = (xb + kXOff) & ~3;
-  const int xoff = (xb + kXOff) - a0 + 3;
-  const int ndw = (xoff + 3 + wi + 3) >> 2;
-  const uint8_t* base = pyr + (size_t)f * P.slab + L.off + (size_t)(iniY + kEdge) * L.pitch + a0;
+  // stage the view, dword-aligned on the slab: a wave per row.  LDS column 0 is the slab column
+  // of the view's first dword; interior pixel x sits in LDS column x + xoff.
+  const int xoff = item.xoff;
+  const int ndw = item.ndw;
+  struct { int pitch, cand_off, cand_cap; } L = {item.pitch, item.cand_off, item.cand_cap};
+  const uint8_t* base = pyr + (size_t)f * P.slab + (uint32_t)item.base_off;
   {
     // all of this wave's rows are requested before the first one is waited for (one memory
     // latency per workgroup, not one per four rows), and the V map is cleared in between
@@ -905,8 +903,8 @@ __device__ __forceinline__ void fast_body(const uint8_t* __restrict__ pyr, const
 constexpr int F_PITCH_NARROW = 224;
 constexpr int F_USEW_NARROW = 208;
 static_assert(3 + F_USEW_NARROW + 6 + 3 <= F_PITCH_NARROW, "a narrow staged row must fit its pitch");
-__global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, Plan P,
-                                                         const FastItem* __restrict__ items,
+__global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restrict__ pyr, FastPlan P,
+                                                         const FastWork* __restrict__ items,
                                                          uint32_t* __restrict__ cand_all,
                                                          int* __restrict__ cand_cnt, int iniTh, int minTh,
                                                          int wide_rows, int narrow_rows) {
@@ -917,8 +915,8 @@ __global__ __launch_bounds__(F_THREADS) void fast_kernel(const uint8_t* __restri
   __shared__ int s_cnt[F_MAXCELLS];
   __shared__ int s_vars[3];
   const FastShared S{s_dyn, s_list, s_corner, s_ncorner, s_cnt, s_vars};
-  const FastItem item = items[blockIdx.y];
-  if (P.lv[item.level].hCell + 6 <= wide_rows) fast_body<F_PITCH>(pyr, P, item, cand_all, cand_cnt, iniTh, minTh, wide_rows, S);
+  const FastWork item = items[blockIdx.y];
+  if (item.hCell + 6 <= wide_rows) fast_body<F_PITCH>(pyr, P, item, cand_all, cand_cnt, iniTh, minTh, wide_rows, S);
   else fast_body<F_PITCH_NARROW>(pyr, P, item, cand_all, cand_cnt, iniTh, minTh, narrow_rows, S);
 }
 
@@ -2088,8 +2086,9 @@ int fast_use_width_narrow() { return F_USEW_NARROW; }
 // (see fast_kernel; they come first: the longest workgroups should not be the last to start), the
 // others follow.  ntall < 0: one launch, everything at the wide pitch with room for the tallest view
 // (launches of a few frames: occupancy does not matter).
-void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int nitems, int ntall, uint32_t* cand,
+void launch_fast(const uint8_t* pyr, const Plan& P, const FastWork* items, int nitems, int ntall, uint32_t* cand,
                  int* cand_cnt, int iniTh, int minTh, int nframes, hipStream_t st) {
+  const FastPlan FPn{P.slab, P.cand_total, P.nlevels};
   int rows = 7;
   for (int l = 0; l < P.nlevels; l++) rows = max(rows, P.lv[l].hCell + 6);
   rows = min(rows, F_MAXH);
@@ -2097,21 +2096,21 @@ void launch_fast(const uint8_t* pyr, const Plan& P, const FastItem* items, int n
   if (ntall >= 0 && rows > dense && rows <= fast_rows_narrow()) {
     // one launch, two kinds of workgroup, the same LDS footprint
     const size_t lds = max((2 * (size_t)dense - 4) * F_PITCH, (2 * (size_t)rows - 4) * F_PITCH_NARROW);
-    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), lds, st, pyr, P, items, cand, cand_cnt, iniTh,
+    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), lds, st, pyr, FPn, items, cand, cand_cnt, iniTh,
                        minTh, dense, rows);
     return;
   }
   if (ntall > 0 && ntall < nitems && rows > dense) {
     // views too tall even for the narrow pitch: those with room for the tallest, then the others
     // with the small footprint
-    hipLaunchKernelGGL(fast_kernel, dim3(nframes, ntall), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, P, items,
+    hipLaunchKernelGGL(fast_kernel, dim3(nframes, ntall), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, FPn, items,
                        cand, cand_cnt, iniTh, minTh, rows, rows);
     hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems - ntall), dim3(F_THREADS), (2 * (size_t)dense - 4) * F_PITCH, st, pyr,
-                       P, items + ntall, cand, cand_cnt, iniTh, minTh, dense, dense);
+                       FPn, items + ntall, cand, cand_cnt, iniTh, minTh, dense, dense);
     return;
   }
   if (nitems > 0)
-    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, P, items,
+    hipLaunchKernelGGL(fast_kernel, dim3(nframes, nitems), dim3(F_THREADS), (2 * (size_t)rows - 4) * F_PITCH, st, pyr, FPn, items,
                        cand, cand_cnt, iniTh, minTh, rows, rows);
 }
 template <int MAXS, int THREADS>
