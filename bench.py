@@ -7,10 +7,12 @@ pairs of that batch.  Inputs are synthetic and resident in HBM before the timed 
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 
-For N > 1 launch with torch.distributed.run (one rank per GPU); every rank extracts its
-own batch (weak scaling, no collective on that path).  The Hamming kNN-2 leg shards the
-database over the ranks and merges per-query (best, second, index) after an RCCL
-all-gather.
+For N > 1 there is one process (rank) per GPU: under torch.distributed.run the ranks exist
+already (RANK / WORLD_SIZE in the environment); a plain `python bench.py --gpus N` starts its N
+ranks itself, as child processes, before anything in the parent has touched a GPU, relays rank 0's
+line and exits non-zero if any rank did.  Every rank extracts its own batch (weak scaling, no
+collective on that path).  The Hamming kNN-2 leg shards the database over the ranks and merges
+per-query (best, second, index) records after an RCCL all-gather.
 
 Rank 0 prints one JSON line.
 """
@@ -18,6 +20,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,6 +55,52 @@ def algorithmic_bytes(rows, cols, blur_fused=False):
     return {"pyramid": (S0 + (S - S7)) + P, "fast": P, "orient_desc" if blur_fused else "blur": 2 * S}
 
 
+def spawn_ranks(cmd, n, env=None, grace_s=20.0, poll_s=0.2):
+    """Runs `cmd` (an argv list) as n child processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, waits for all of them and returns (exit code, rank 0's stdout as
+    bytes).  Rank 0's stdout is captured; the other ranks' stdout goes to this process's stderr.
+    The exit code is 0 only if every rank's was; once a rank has failed the others get grace_s
+    seconds to end by themselves (they may be waiting for it in a collective) and are then ended,
+    each by its own process id.  The caller must not have touched a GPU: the children are plain
+    child processes, nothing is replaced."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stdin=subprocess.DEVNULL))
+    out0 = []
+    import threading
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed_at = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.monotonic() + 5.0
+            while time.monotonic() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(poll_s)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(poll_s)
+    reader.join(10.0)
+    codes = [p.wait() for p in procs]
+    rc = next((c for c in codes if c != 0), 0)
+    return (rc if rc > 0 else (1 if rc != 0 else 0)), (out0[0] if out0 else b"")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,11 +114,21 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--knn-reps", type=int, default=3, help="timed repetitions of the kNN-2 leg (the median is reported)")
     ap.add_argument("--knn-popcount", type=int, default=1, help="1: also time the popcount kernel once on the same input")
-    ap.add_argument("--knn-comm", choices=["torch", "rccl"], default="torch",
-                    help="exchange of the sharded kNN-2 for N > 1: torch.distributed all_gather + orb_knn2_merge_device "
-                         "(the code the gloo test runs), or the library's own orb_knn2_sharded (ncclAllGather inside)")
+    ap.add_argument("--knn-comm", choices=["auto", "torch", "rccl"], default="auto",
+                    help="exchange of the sharded kNN-2 for N > 1: the library's own orb_knn2_sharded (ncclAllGather "
+                         "inside: what a C++ host gets; the default), or torch.distributed all_gather + "
+                         "orb_knn2_merge_packed_device (the code the gloo test runs; the default when the ranks share "
+                         "one GPU, where RCCL cannot be used)")
     ap.add_argument("--host-reps", type=int, default=5, help="repetitions of the host-buffer batch call (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by a launcher: start the ranks from here (this process has imported nothing
+        # that touches a GPU) and hand rank 0's line on
+        rc, out = spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        sys.stdout.flush()
+        os.write(1, out)
+        sys.exit(rc)
 
     # stdout carries the one JSON line and nothing else: libraries that print banners to file
     # descriptor 1 (RCCL does when a communicator is created) are sent to stderr instead
@@ -82,12 +142,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree\n" % (args.gpus, world))
+        sys.exit(2)
     # Rehearsal on a box with fewer GPUs than ranks: ORBHIP_BENCH_SHARE_GPU=1 puts every rank on GPU 0
     # and the exchange on gloo (RCCL refuses two ranks on one GPU); never set for a measurement.
     share = os.environ.get("ORBHIP_BENCH_SHARE_GPU", "0") == "1"
     if share:
         local = 0
+    knn_comm = args.knn_comm if args.knn_comm != "auto" else ("rccl" if world > 1 and not share else "torch")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -203,6 +266,45 @@ def main():
                 "latency_ms_single_frame": round(1e3 * float(np.median(tl)), 4),
                 "latency_ms_single_frame_p90": round(1e3 * float(np.percentile(tl, 90)), 4)}
         assert int(hn.sum()) == nkp, "host-buffer and device-buffer extraction disagree on the keypoint count"
+        if npairs >= 1:
+            # the call a tracking thread makes next (src/Tracking.cc:1065): SearchByProjection(Cur, Last, 7, mono)
+            # on host arrays, one frame pair (frames 0 and 1 of the batch), host to host
+            s_last = (args.steps - 1) % nsets if args.steps > 0 else 0
+            g_nout, g_kps, g_desc, g_match, g_nm = chain.results(s_last)
+            n0, n1 = int(g_nout[0]), int(g_nout[1])
+            kl, kc = g_kps[0, :n0], g_kps[1, :n1]
+            as_c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+            l_oct, l_ang = as_c(kl["octave"], np.int32), as_c(kl["angle"], np.float32)
+            c_x, c_y = as_c(kc["x"], np.float32), as_c(kc["y"], np.float32)
+            c_oct, c_ang = as_c(kc["octave"], np.int32), as_c(kc["angle"], np.float32)
+            l_desc, c_desc = as_c(g_desc[0, :n0], np.uint8), as_c(g_desc[1, :n1], np.uint8)
+            l_xw = as_c(chain.d_xw[0, :n0].cpu().numpy(), np.float32)
+            l_obs = as_c(chain.d_last_obs[0, :n0].cpu().numpy(), np.int32)
+            tcw = as_c(chain.d_tcw[0].cpu().numpy(), np.float32)
+            c_obs = np.full(n1, -1, np.int32)
+            nl, nc = np.array([n0], np.int32), np.array([n1], np.int32)
+            mt, nm1 = np.zeros(n1, np.int32), np.zeros(1, np.int32)
+            sc = chain.scene
+
+            def host_match():
+                check(L.orb_search_by_projection_frames(
+                    local, 1, n0, n1, tcw.ctypes.data, float(sc.fx), float(sc.fy), float(sc.cx), float(sc.cy),
+                    chain.bounds, chain.sf.ctypes.data, NLEVELS, nl.ctypes.data, l_obs.ctypes.data, l_xw.ctypes.data,
+                    l_desc.ctypes.data, l_oct.ctypes.data, l_ang.ctypes.data, nc.ctypes.data, c_x.ctypes.data,
+                    c_y.ctypes.data, c_oct.ctypes.data, c_ang.ctypes.data, c_desc.ctypes.data, c_obs.ctypes.data,
+                    7.0, 1, mt.ctypes.data, nm1.ctypes.data))
+            for _ in range(3):
+                host_match()
+            assert int(nm1[0]) == int(g_nm[0]) and np.array_equal(mt, g_match[0, :n1]), \
+                "host-buffer and device-buffer SearchByProjection disagree"
+            tm, tt = [], []
+            for _ in range(200):
+                t = time.perf_counter(); host_match(); tm.append(time.perf_counter() - t)
+            for _ in range(200):
+                t = time.perf_counter(); host_batch(1); host_match(); tt.append(time.perf_counter() - t)
+            host["latency_ms_single_pair_match"] = round(1e3 * float(np.median(tm)), 4)
+            host["latency_ms_frame_total"] = round(1e3 * float(np.median(tt)), 4)
+            host["latency_ms_frame_total_p90"] = round(1e3 * float(np.percentile(tt, 90)), 4)
 
     # ---------------- kNN-2 leg (C5 shape, database sharded over the ranks) ----------------
     knn = None
@@ -215,22 +317,28 @@ def main():
         # the code path tests/test_dist_cpu.py runs with gloo: shard scan, one all-gather, merge
         local_search = odist.hip_local_search(d_q, d_db, lo, 0.7, local, stream)
         merge = odist.hip_merge(0.7, local, stream)
+        merge_packed = odist.hip_merge_packed(0.7, local, stream)
         res = torch.zeros((3, nq), dtype=torch.int32, device=dev)
         small = min(nq, 65536)
         check(L.orb_knn2_device(local, d_q.data_ptr(), small, d_db.data_ptr(), min(hi - lo, 65536), lo, 0.7,
                                 res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), None, stream))  # warm-up
         rk = None
-        if args.knn_comm == "rccl" or world == 1:
+        if knn_comm == "rccl" or world == 1:
             rk = odist.RcclKnn(local, rank, world)
-        times = []
+            rk.search(d_q[:small], d_db[:min(hi - lo, 65536)], lo, 0.7, stream)  # communicator and kernels warm
+        times, tparts = [], []
         for _ in range(max(args.knn_reps, 1)):
             barrier()
             tk0 = time.perf_counter()
-            if args.knn_comm == "rccl":
+            if knn_comm == "rccl":
                 out, acc = rk.search(d_q, d_db, lo, 0.7, stream)
             else:
-                out, acc = odist.knn2_sharded(local_search, merge, nq, dev, world)
+                tm_ = {}
+                out, acc = odist.knn2_sharded(local_search, merge, nq, dev, world, merge_packed=merge_packed, timings=tm_)
+                tparts.append((1e3 * tm_["scan_s"], 1e3 * tm_["exchange_s"]))
             barrier()
+            if knn_comm == "rccl":
+                tparts.append(rk.times())
             tk = torch.tensor([time.perf_counter() - tk0], dtype=torch.float64, device=red)
             if world > 1:
                 dist.all_reduce(tk, op=dist.ReduceOp.MAX)
@@ -241,8 +349,20 @@ def main():
                "seconds_all": [round(t, 4) for t in times],
                "matches_per_s": round(nq / tk, 1), "pairs_per_s": round(pairs / tk, 1),
                "accepted": int(acc.sum().item())}
-        knn["exchange"] = args.knn_comm
-        if rk is not None and args.knn_comm != "rccl":
+        # the exchange step on its own: all-gather + merge (rccl: HIP events on the stream inside the
+        # library; torch: host clock around the collective and the merge, device synchronised), and
+        # how many ranks the collective really had
+        parts = torch.tensor([float(np.median([p[0] for p in tparts])), float(np.median([p[1] for p in tparts]))],
+                             dtype=torch.float64, device=red)
+        if world > 1:
+            dist.all_reduce(parts, op=dist.ReduceOp.MAX)
+        knn["exchange"] = {"via": "orb_knn2_sharded (ncclAllGather in the library)" if knn_comm == "rccl" else
+                           "torch.distributed.all_gather_into_tensor (%s) + orb_knn2_merge_packed_device" % (dist.get_backend() if world > 1 else "none"),
+                           "bytes_per_query_per_rank": 8}
+        knn["scan_ms"] = round(float(parts[0].item()), 3)
+        knn["exchange_ms"] = round(float(parts[1].item()), 3)
+        knn["ranks_in_collective"] = rk.info()[2] if knn_comm == "rccl" else (dist.get_world_size() if world > 1 else 1)
+        if rk is not None and knn_comm != "rccl":
             # one GPU: the library's own sharded entry point on a communicator of one rank, same input
             o2, a2 = rk.search(d_q, d_db, lo, 0.7, stream)  # allocates its exchange buffers
             barrier()
@@ -250,7 +370,9 @@ def main():
             o2, a2 = rk.search(d_q, d_db, lo, 0.7, stream)
             barrier()
             knn["c_abi_sharded"] = {"seconds": round(time.perf_counter() - tk0, 4),
-                                    "identical": bool(torch.equal(o2, out) and torch.equal(a2, acc))}
+                                    "identical": bool(torch.equal(o2, out) and torch.equal(a2, acc)),
+                                    "scan_ms": round(rk.times()[0], 3), "exchange_ms": round(rk.times()[1], 3),
+                                    "ranks_in_collective": rk.info()[2]}
         if rk is not None:
             rk.close()
         mfma = hi - lo >= 2048 and nq >= 256

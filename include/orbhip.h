@@ -12,11 +12,15 @@
  * keypoint buffers are shared by every call on it, so two calls that overlap (two threads, or
  * orb_extract_batch_device on two streams without an event between them) race.  Distinct handles
  * are independent.  The first call of a handle at a new image size, or with more frames than any
- * call before, allocates and waits for the device; later calls only enqueue.
- * The host-buffer matcher entry points keep no state and may be called concurrently from several
- * threads (the reference calls them from its tracking, mapping and loop-closing threads): each
- * call runs on a stream of its own, waits only for that stream, and never for the null stream or
- * the whole device.
+ * call before, allocates and waits for the handle's own earlier work; later calls only enqueue.
+ * The host-buffer matcher entry points (and orb_distinctive_descriptors, orb_bow_transform,
+ * orb_undistort_points) keep no state and may be called concurrently from several threads (the
+ * reference calls them from its tracking, mapping and loop-closing threads): each call runs on a
+ * stream of its own and waits only for that stream.  Device memory of handles and calls comes from
+ * the device's stream-ordered pool (hipMallocAsync / hipFreeAsync on the handle's or call's own
+ * stream), so neither a first call nor a growing one waits for other threads' work; on a device
+ * without memory pools (or with ORBHIP_ASYNC_ALLOC=0 in the environment) plain hipMalloc / hipFree
+ * are used instead, and a first or growing call then waits for the whole device.
  */
 #ifndef ORBHIP_H_
 #define ORBHIP_H_
@@ -122,7 +126,9 @@ int orb_extractor_set_input_format(OrbExtractor* h, int channels, int rgb_order)
  *   cv::cvtColor to grey (src/Tracking.cc:203-216, see orb_extractor_set_input_format): 15-bit
  *     weights from 4.0 on, 14-bit weights (R*4899 + G*9617 + B*1868 + 2^13) >> 14 before.
  * Default: 4.5 and later.  Releases before 3.4 blur in floating point and are refused with
- * ORBHIP_ERR_UNSUPPORTED.  No counterpart in the reference. */
+ * ORBHIP_ERR_UNSUPPORTED.  No counterpart in the reference.  The release boundaries above are
+ * taken from OpenCV's history as restated here, not from anything the reference holds: they are
+ * unverified against a real OpenCV build (a late 3.4.x may already carry the 4.5 taps). */
 int orb_extractor_set_opencv_compat(OrbExtractor* h, int major, int minor);
 
 /* Where the 7x7 blur of src/ORBextractor.cc:1297-1305 is done.  fused != 0 (the default): the
@@ -248,7 +254,9 @@ int orb_search_by_projection_frames_device(
  * arrays live in a fixed array inside the library, ORBHIP_NOALLOC_MAX_QUERIES * 60 + 64 bytes
  * (3.75 MiB) on every GPU the library is used on, held until the process ends; the call fails
  * with ORBHIP_ERR_CAPACITY if n_pairs * max_last exceeds ORBHIP_NOALLOC_MAX_QUERIES.  It calls no
- * hipMalloc / hipFree; the first call on a device looks the array's address up once.  All calls
+ * hipMalloc / hipFree; the first call on a device looks the array's address up once
+ * (hipGetSymbolAddress) and raises the kernel's dynamic-LDS limit (hipFuncSetAttribute): make one
+ * call per device outside stream capture before capturing one.  All calls
  * on one GPU share that array: calls that overlap in time on one GPU (different streams or
  * threads) race and must be serialised by the caller.  Inputs, outputs and results as in
  * orb_search_by_projection_frames_device. */
@@ -424,15 +432,33 @@ int orb_knn2_device_algo(int device_id, const uint8_t* d_q, int n_q, const uint8
 int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_best,
                           const int* d_second, const int* d_idx, float ratio, int* d_out_best,
                           int* d_out_second, int* d_out_idx, uint8_t* d_out_accept, void* stream);
+/* The per-query result of a shard as one 8-byte record, the form in which ranks exchange it:
+ * word 0 = best | second << 16 (distances are at most 256), word 1 = global row (0xFFFFFFFF =
+ * none).  orb_knn2_pack_device writes d_packed[n_q] records from the three arrays of
+ * orb_knn2_device; orb_knn2_merge_packed_device is orb_knn2_merge_device on records laid out
+ * [n_shards][n_q].  Device pointers, 8-byte aligned; enqueued on `stream`.  No counterpart in the
+ * reference. */
+int orb_knn2_pack_device(int device_id, int n_q, const int* d_best, const int* d_second,
+                         const int* d_idx, void* d_packed, void* stream);
+int orb_knn2_merge_packed_device(int device_id, int n_shards, int n_q, const void* d_packed,
+                                 float ratio, int* d_out_best, int* d_out_second, int* d_out_idx,
+                                 uint8_t* d_out_accept, void* stream);
 /* The same search with the database sharded over the GPUs of a node, one process (rank) per GPU.
  * No counterpart in the reference, which has no multi-device code.  Rank r holds the database
  * rows [db_index_base, db_index_base + n_db_shard): the shards are contiguous and ascend with
- * the rank; the queries are replicated.  orb_knn2_sharded scans the local shard, exchanges the
- * per-query (best, second, index) triples with ONE ncclAllGather (12 bytes x n_q per rank, RCCL
- * over xGMI) and merges them in rank order, so every rank ends up with the result of a single
- * scan of the whole database, bit for bit (the earlier shard keeps ties).  Everything is enqueued
- * on `stream`; the first call, and a call with more queries than any before, allocates the
- * exchange buffers (3 * n_q * (world + 1) ints) and waits for the stream first.
+ * the rank; the queries are replicated, and n_q must be the same number on every rank.
+ * orb_knn2_sharded scans the local shard, exchanges the per-query records (above) with ONE
+ * ncclAllGather (8 bytes x n_q per rank, RCCL over xGMI) and merges them in rank order, so every
+ * rank ends up with the result of a single scan of the whole database, bit for bit (the earlier
+ * shard keeps ties).  Everything is enqueued on `stream`; the first call, and a call with more
+ * queries than any before, allocates the exchange buffers (n_q * (20 + 8 * world) bytes) and
+ * waits for the stream first.
+ * The call is collective: arguments are checked before any work, so a call that returns
+ * ORBHIP_ERR_ARG has not entered the collective, and callers that pass the same kind of arguments
+ * on every rank fail on every rank alike.  A failure after the checks (allocation, kernel launch)
+ * on one rank cannot be reported to the others; a communicator the library created is then
+ * aborted (ncclCommAbort), so that the other ranks' pending all-gather ends with an error instead
+ * of waiting for ever, and refuses further calls.  A wrapped communicator is left to its owner.
  *   orb_knn2_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the
  *                             other ranks by its own means (MPI, a file, torch.distributed ...)
  *   orb_knn2_comm_create      every rank, collectively (ncclCommInitRank) on GPU device_id
@@ -444,6 +470,14 @@ int orb_knn2_comm_unique_id(uint8_t* id /* ORBHIP_KNN_UNIQUE_ID_BYTES */);
 int orb_knn2_comm_create(const uint8_t* id, int rank, int world, int device_id, OrbKnnComm** out);
 int orb_knn2_comm_wrap(void* nccl_comm, int rank, int world, int device_id, OrbKnnComm** out);
 void orb_knn2_comm_destroy(OrbKnnComm* c);
+/* This handle's rank and world size as given at creation, and the number of ranks the
+ * communicator itself reports (ncclCommCount; -1 if RCCL does not offer it).  Null pointers are
+ * skipped. */
+int orb_knn2_comm_info(OrbKnnComm* c, int* rank, int* world, int* ranks_in_collective);
+/* Milliseconds the last orb_knn2_sharded call on this handle spent, by HIP events on its stream,
+ * in the shard scan (with packing) and in the exchange (all-gather + merge).  Waits for that
+ * call.  Null pointers are skipped. */
+int orb_knn2_sharded_times(OrbKnnComm* c, float* scan_ms, float* exchange_ms);
 int orb_knn2_sharded(OrbKnnComm* c, const uint8_t* d_q, int n_q, const uint8_t* d_db_shard,
                      int n_db_shard, int db_index_base, float ratio, int* d_best, int* d_second,
                      int* d_idx, uint8_t* d_accept, void* stream);

@@ -42,6 +42,7 @@ EXPORTS = [
     "orb_get_pyramid_level", "orb_get_blurred_level", "orb_get_fast_candidates", "orb_get_level_keypoints",
     "orb_hamming_distance_pairs", "orb_search_by_projection_frames", "orb_search_by_projection_mappoints",
     "orb_search_for_triangulation", "orb_knn2_device", "orb_knn2_device_algo", "orb_knn2_merge_device", "orb_knn2_bruteforce", "orb_knn2_comm_unique_id", "orb_knn2_comm_create", "orb_knn2_comm_wrap", "orb_knn2_comm_destroy", "orb_knn2_sharded",
+    "orb_knn2_pack_device", "orb_knn2_merge_packed_device", "orb_knn2_comm_info", "orb_knn2_sharded_times",
     "orb_vocabulary_create", "orb_vocabulary_destroy", "orb_bow_transform_device", "orb_bow_transform", "orb_distinctive_descriptors",
     "orb_undistort_keypoints_device", "orb_undistort_points", "orb_compute_image_bounds",
 ]
@@ -112,6 +113,10 @@ def lib():
     L.orb_knn2_comm_destroy.argtypes = [vp]
     L.orb_knn2_comm_destroy.restype = None
     L.orb_knn2_sharded.argtypes = [vp, vp, i, vp, i, i, f, vp, vp, vp, vp, vp]
+    L.orb_knn2_pack_device.argtypes = [i, i, vp, vp, vp, vp, vp]
+    L.orb_knn2_merge_packed_device.argtypes = [i, i, i, vp, f, vp, vp, vp, vp, vp]
+    L.orb_knn2_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.orb_knn2_sharded_times.argtypes = [vp, C.POINTER(f), C.POINTER(f)]
     L.orb_knn2_bruteforce.argtypes = [i, vp, i, vp, i, f, vp, vp, vp, vp]
     L.orb_vocabulary_create.argtypes = [i, i, i, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.orb_vocabulary_destroy.argtypes = [vp]

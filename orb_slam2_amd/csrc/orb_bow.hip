@@ -5,6 +5,7 @@
 // The ordered maps that transform(features, v, fv, levelsup) (:1141-1208) builds from the
 // (word, node) pairs stay with the caller.
 #include "orb_common.h"
+#include "orb_hostbuf.h"
 
 #include <string>
 #include <vector>
@@ -18,7 +19,6 @@ struct OrbVocabulary {
   int* d_word = nullptr;
   uint8_t* d_desc = nullptr;
   // staging for one call (grow-only)
-  uint8_t* d_q = nullptr; int* d_out = nullptr; size_t q_cap = 0;
 };
 
 namespace orbhip {
@@ -132,7 +132,6 @@ void orb_vocabulary_destroy(OrbVocabulary* v) {
   if (prev != v->device) hipSetDevice(v->device);
   hipDeviceSynchronize();
   hipFree(v->d_child_start); hipFree(v->d_child_count); hipFree(v->d_children); hipFree(v->d_word); hipFree(v->d_desc);
-  hipFree(v->d_q); hipFree(v->d_out);
   if (prev >= 0 && prev != v->device) hipSetDevice(prev);
   delete v;
 }
@@ -160,28 +159,20 @@ int orb_bow_transform(OrbVocabulary* v, int n, const uint8_t* desc, int levelsup
   if (!v) { set_error("null vocabulary"); return ORBHIP_ERR_ARG; }
   if (n <= 0) return ORBHIP_OK;
   if (!desc || !word_id || !node_id) { set_error("null argument"); return ORBHIP_ERR_ARG; }
-  int prev = -1;
-  hipGetDevice(&prev);
-  if (prev != v->device) ORB_HIP_CHECK(hipSetDevice(v->device));
-  int rc = ORBHIP_OK;
-  hipError_t e = hipSuccess;
-  if ((size_t)n > v->q_cap) {
-    hipFree(v->d_q); hipFree(v->d_out); v->d_q = nullptr; v->d_out = nullptr; v->q_cap = 0;
-    e = hipMalloc(&v->d_q, (size_t)32 * n);
-    if (e == hipSuccess) e = hipMalloc(&v->d_out, sizeof(int) * 2 * (size_t)n);
-    if (e == hipSuccess) v->q_cap = (size_t)n;
-  }
-  if (e == hipSuccess) e = hipMemcpy(v->d_q, desc, (size_t)32 * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    rc = orb_bow_transform_device(v, n, v->d_q, levelsup, v->d_out, v->d_out + n, nullptr);
-    if (rc == ORBHIP_OK) {
-      e = hipMemcpy(word_id, v->d_out, sizeof(int) * n, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(node_id, v->d_out + n, sizeof(int) * n, hipMemcpyDeviceToHost);
-    }
-  }
-  if (prev >= 0 && prev != v->device) hipSetDevice(prev);
-  if (e != hipSuccess) return hip_fail(e, "orb_bow_transform");
-  return rc;
+  // a stream and arena of the call's own: Frame::ComputeBoW and KeyFrame::ComputeBoW run on the
+  // tracking, mapping and loop-closing threads with one shared vocabulary
+  DevSel g(v->device);
+  DevBuf buf;
+  uint8_t* d_q = nullptr;
+  int* d_out = nullptr;
+  UP(buf, desc, (size_t)32 * n, d_q);
+  UP(buf, (const int*)nullptr, 2 * (size_t)n, d_out);
+  const int rc = orb_bow_transform_device(v, n, d_q, levelsup, d_out, d_out + n, buf.stream());
+  if (rc != ORBHIP_OK) return rc;
+  DOWN(buf, word_id, d_out, (size_t)n);
+  DOWN(buf, node_id, d_out + n, (size_t)n);
+  SYNC(buf);
+  return ORBHIP_OK;
 }
 
 }  // extern "C"

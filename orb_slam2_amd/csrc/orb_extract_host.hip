@@ -217,11 +217,21 @@ struct OrbExtractor {
   // kernels, four copies): its device work is captured once into a graph and replayed while
   // nothing the graph refers to (sizes, buffers, tables) has changed.
   hipGraphExec_t graph_exec = nullptr;
+  // Last device-buffer call: an event on the caller's stream, so that a later call that has to
+  // reallocate, and the accessors, wait for that call's work instead of for the whole device.
+  hipEvent_t done_ev = nullptr;
+  bool done_pending = false;
+  bool async_alloc = false;  // the device has stream-ordered memory pools: buffers come from hipMallocAsync
   struct GraphKey {
     int n_frames = 0, rows = 0, cols = 0, max_kp = 0, channels = 0, rgb = 0, fused = 0;
     int taps[4] = {0, 0, 0, 0}, gray[4] = {0, 0, 0, 0};
     const void *d_img = nullptr, *h_img = nullptr, *h_out = nullptr, *d_kps = nullptr, *d_pyr = nullptr;
-    bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
+    bool operator==(const GraphKey& o) const {
+      return n_frames == o.n_frames && rows == o.rows && cols == o.cols && max_kp == o.max_kp && channels == o.channels &&
+             rgb == o.rgb && fused == o.fused && memcmp(taps, o.taps, sizeof(taps)) == 0 &&
+             memcmp(gray, o.gray, sizeof(gray)) == 0 && d_img == o.d_img && h_img == o.h_img && h_out == o.h_out &&
+             d_kps == o.d_kps && d_pyr == o.d_pyr;
+    }
   } graph_key;
 };
 
@@ -241,11 +251,47 @@ static int pool_threads() {
 }
 constexpr size_t kPoolMinBytes = (size_t)4 << 20;  // smaller batches are packed by the caller alone
 
+// Device buffers of a handle come from the device's stream-ordered pool, allocated and freed on the
+// handle's own stream: hipMalloc / hipFree wait for every stream of the device, which would make a
+// tracking thread that changes its image size wait for the mapping and loop-closing threads' work.
+// (Devices without memory pools fall back to hipMalloc / hipFree.)
+template <typename T>
+hipError_t dev_alloc(OrbExtractor* h, T** p, size_t bytes) {
+  bytes = std::max<size_t>(bytes, 16);
+  if (h->async_alloc) return hipMallocAsync(reinterpret_cast<void**>(p), bytes, h->stream);
+  return hipMalloc(reinterpret_cast<void**>(p), bytes);
+}
+void dev_free(OrbExtractor* h, void* p) {
+  if (!p) return;
+  if (h->async_alloc) hipFreeAsync(p, h->stream);
+  else hipFree(p);
+}
+
+// The captured graph refers to the handle's buffers by address: it goes whenever one of them does.
+void drop_graph(OrbExtractor* h) {
+  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+}
+
+// Waits for everything this handle has queued, on its own streams and on the stream of the last
+// device-buffer call; other handles' and other threads' streams are not waited for.
+hipError_t wait_own(OrbExtractor* h) {
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return e;
+  if (h->up && (e = hipStreamSynchronize(h->up)) != hipSuccess) return e;
+  if (h->down && (e = hipStreamSynchronize(h->down)) != hipSuccess) return e;
+  if (h->done_pending) {
+    if ((e = hipEventSynchronize(h->done_ev)) != hipSuccess) return e;
+    h->done_pending = false;
+  }
+  return hipSuccess;
+}
+
 void free_plan_buffers(OrbExtractor* h) {
-  hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_xtab); hipFree(h->d_ytab);
-  hipFree(h->d_fast_items); hipFree(h->d_blur_items); hipFree(h->d_cand); hipFree(h->d_pnode);
-  hipFree(h->d_sel); hipFree(h->d_cand_cnt); hipFree(h->d_sel_cnt);
-  hipFree(h->d_xtp); hipFree(h->d_ranges);
+  drop_graph(h);
+  dev_free(h, h->d_pyr); dev_free(h, h->d_blur); dev_free(h, h->d_xtab); dev_free(h, h->d_ytab);
+  dev_free(h, h->d_fast_items); dev_free(h, h->d_blur_items); dev_free(h, h->d_cand); dev_free(h, h->d_pnode);
+  dev_free(h, h->d_sel); dev_free(h, h->d_cand_cnt); dev_free(h, h->d_sel_cnt);
+  dev_free(h, h->d_xtp); dev_free(h, h->d_ranges);
   h->d_xtp = nullptr; h->d_ranges = nullptr;
   h->d_pyr = h->d_blur = nullptr; h->d_xtab = nullptr; h->d_ytab = nullptr;
   h->d_fast_items = nullptr; h->d_blur_items = nullptr;
@@ -393,15 +439,15 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
   const size_t n_tall = std::stable_partition(fi.begin(), fi.end(), [&](const FastItem& it) {
                           return P.lv[it.level].hCell + 6 > dense_rows; }) - fi.begin();
   fi.insert(fi.end(), fi_few.begin(), fi_few.end());  // one device array: the items for batches, then those for a few frames
-  ORB_HIP_CHECK(hipDeviceSynchronize());
+  ORB_HIP_CHECK(wait_own(h));
   const int cap = std::max(nframes, (h->have_plan && h->plan.rows == rows && h->plan.cols == cols) ? h->cap_frames : 0);
   free_plan_buffers(h);
-  ORB_HIP_CHECK(hipMalloc(&h->d_pyr, P.slab * cap));
-  ORB_HIP_CHECK(hipMalloc(&h->d_blur, P.slab * cap));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_pyr, P.slab * cap));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_blur, P.slab * cap));
   ORB_HIP_CHECK(hipMemsetAsync(h->d_pyr, 0, P.slab * cap, h->stream));
   ORB_HIP_CHECK(hipMemsetAsync(h->d_blur, 0, P.slab * cap, h->stream));
-  ORB_HIP_CHECK(hipMalloc(&h->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1)));
-  ORB_HIP_CHECK(hipMalloc(&h->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1)));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1)));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1)));
   // the items as the kernel reads them (see FastWork; the same arithmetic the kernel used to do per workgroup)
   std::vector<FastWork> fw(fi.size());
   for (size_t i = 0; i < fi.size(); i++) {
@@ -418,8 +464,8 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
     w.tw = (int16_t)(xe - xb); w.th = (int16_t)(maxY - iniY); w.xb = (int16_t)xb; w.iniY = (int16_t)iniY;
     w.xoff = (int16_t)xoff; w.ndw = (int16_t)((xoff + 3 + wi + 3) >> 2);
   }
-  ORB_HIP_CHECK(hipMalloc(&h->d_fast_items, sizeof(FastWork) * fw.size()));
-  ORB_HIP_CHECK(hipMalloc(&h->d_blur_items, sizeof(BlurItem) * bi.size()));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_fast_items, sizeof(FastWork) * fw.size()));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_blur_items, sizeof(BlurItem) * bi.size()));
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_xtab, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice, h->stream));
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_ytab, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice, h->stream));
   ORB_HIP_CHECK(hipMemcpyAsync(h->d_fast_items, fw.data(), sizeof(FastWork) * fw.size(), hipMemcpyHostToDevice, h->stream));
@@ -506,16 +552,17 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
       pi.ok = rows1 <= 64 && pi.lds <= 60 * 1024;
       h->pair[l] = pi;
     }
-    ORB_HIP_CHECK(hipMalloc(&h->d_xtp, sizeof(uint32_t) * std::max<size_t>(xtp.size(), 4)));
-    ORB_HIP_CHECK(hipMalloc(&h->d_ranges, sizeof(int2) * std::max<size_t>(ranges.size(), 1)));
-    ORB_HIP_CHECK(hipMemcpy(h->d_xtp, xtp.data(), sizeof(uint32_t) * xtp.size(), hipMemcpyHostToDevice));
-    ORB_HIP_CHECK(hipMemcpy(h->d_ranges, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice));
+    ORB_HIP_CHECK(dev_alloc(h, &h->d_xtp, sizeof(uint32_t) * std::max<size_t>(xtp.size(), 4)));
+    ORB_HIP_CHECK(dev_alloc(h, &h->d_ranges, sizeof(int2) * std::max<size_t>(ranges.size(), 1)));
+    ORB_HIP_CHECK(hipMemcpyAsync(h->d_xtp, xtp.data(), sizeof(uint32_t) * xtp.size(), hipMemcpyHostToDevice, h->stream));
+    ORB_HIP_CHECK(hipMemcpyAsync(h->d_ranges, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice, h->stream));
+    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));  // xtp and ranges go out of scope
   }
-  ORB_HIP_CHECK(hipMalloc(&h->d_cand, sizeof(uint32_t) * (size_t)P.cand_total * cap));
-  ORB_HIP_CHECK(hipMalloc(&h->d_pnode, sizeof(uint32_t) * (size_t)P.cand_total * cap));
-  ORB_HIP_CHECK(hipMalloc(&h->d_sel, sizeof(uint32_t) * (size_t)P.sel_total * cap));
-  ORB_HIP_CHECK(hipMalloc(&h->d_cand_cnt, sizeof(int) * (size_t)P.nlevels * cap));
-  ORB_HIP_CHECK(hipMalloc(&h->d_sel_cnt, sizeof(int) * (size_t)P.nlevels * cap));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_cand, sizeof(uint32_t) * (size_t)P.cand_total * cap));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_pnode, sizeof(uint32_t) * (size_t)P.cand_total * cap));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_sel, sizeof(uint32_t) * (size_t)P.sel_total * cap));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_cand_cnt, sizeof(int) * (size_t)P.nlevels * cap));
+  ORB_HIP_CHECK(dev_alloc(h, &h->d_sel_cnt, sizeof(int) * (size_t)P.nlevels * cap));
   ORB_HIP_CHECK(hipMemsetAsync(h->d_sel_cnt, 0, sizeof(int) * (size_t)P.nlevels * cap, h->stream));
   ORB_HIP_CHECK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
   h->plan = P; h->fast_items = fi; h->blur_items = bi;
@@ -687,8 +734,16 @@ int orb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini
   DeviceGuard g(device_id);
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate"); }
+  e = hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming);
+  if (e != hipSuccess) { hipStreamDestroy(h->stream); delete h; return hip_fail(e, "hipEventCreate"); }
+  {
+    int pools = 0;
+    const char* env = getenv("ORBHIP_ASYNC_ALLOC");  // 0: plain hipMalloc / hipFree (for comparisons)
+    if (hipDeviceGetAttribute(&pools, hipDeviceAttributeMemoryPoolsSupported, device_id) != hipSuccess) pools = 0;
+    h->async_alloc = pools != 0 && !(env && env[0] == '0');
+  }
   e = upload_orient_tables();
-  if (e != hipSuccess) { hipStreamDestroy(h->stream); delete h; return hip_fail(e, "hipMemcpyToSymbol"); }
+  if (e != hipSuccess) { hipEventDestroy(h->done_ev); hipStreamDestroy(h->stream); delete h; return hip_fail(e, "hipMemcpyToSymbol"); }
   *out = h;
   return ORBHIP_OK;
 }
@@ -696,15 +751,16 @@ int orb_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini
 void orb_extractor_destroy(OrbExtractor* h) {
   if (!h) return;
   DeviceGuard g(h->device);
-  hipDeviceSynchronize();
+  wait_own(h);
   free_plan_buffers(h);
-  hipFree(h->d_img); hipFree(h->d_desc);  // (keypoints and counts live in the descriptors' allocation)
+  dev_free(h, h->d_img); dev_free(h, h->d_desc);  // (keypoints and counts live in the descriptors' allocation)
+  hipStreamSynchronize(h->stream);  // the frees above are ordered on the handle's stream
   if (h->h_img) hipHostFree(h->h_img);
-  if (h->h_out) hipHostFree(h->h_out);
+  { drop_graph(h); if (h->h_out) hipHostFree(h->h_out); }
   delete h->pool;
   for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
-  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
   for (hipEvent_t e : h->pipe_ev) if (e) hipEventDestroy(e);
+  if (h->done_ev) hipEventDestroy(h->done_ev);
   if (h->up) hipStreamDestroy(h->up);
   if (h->down) hipStreamDestroy(h->down);
   hipStreamDestroy(h->stream);
@@ -754,8 +810,18 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
   DeviceGuard g(h->device);
   int rc = ensure_plan(h, rows, cols, n_frames);
   if (rc != ORBHIP_OK) return rc;
-  return enqueue(h, n_frames, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out,
-                 (hipStream_t)stream);
+  rc = enqueue(h, n_frames, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out,
+               (hipStream_t)stream);
+  if (rc != ORBHIP_OK) return rc;
+  // where this call's work ends on the caller's stream (a stream that is being captured into a graph
+  // takes no such event: the capture's owner orders the replays)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (cap == hipStreamCaptureStatusNone) {
+    ORB_HIP_CHECK(hipEventRecord(h->done_ev, (hipStream_t)stream));
+    h->done_pending = true;
+  }
+  return ORBHIP_OK;
 }
 
 int orb_extractor_set_input_format(OrbExtractor* h, int channels, int rgb_order) {
@@ -785,7 +851,7 @@ int orb_extractor_set_blur_fusion(OrbExtractor* h, int fused) {
 int orb_extractor_sync(OrbExtractor* h) {
   if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
   DeviceGuard g(h->device);
-  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  ORB_HIP_CHECK(wait_own(h));
   return ORBHIP_OK;
 }
 
@@ -827,22 +893,26 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   DeviceGuard g(h->device);
   int rc = ensure_plan(h, rows, cols, n_frames);
   if (rc != ORBHIP_OK) return rc;
+  // a device-buffer call on another stream may still be using the handle's buffers
+  if (h->done_pending) ORB_HIP_CHECK(hipStreamWaitEvent(h->stream, h->done_ev, 0));
   const size_t img_bytes = (size_t)rows * row_bytes * n_frames;
   if (img_bytes > h->d_img_bytes) {
-    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
-    hipFree(h->d_img); h->d_img = nullptr; h->d_img_bytes = 0;
-    ORB_HIP_CHECK(hipMalloc(&h->d_img, img_bytes));
+    ORB_HIP_CHECK(wait_own(h));
+    drop_graph(h);
+    dev_free(h, h->d_img); h->d_img = nullptr; h->d_img_bytes = 0;
+    ORB_HIP_CHECK(dev_alloc(h, &h->d_img, img_bytes));
     h->d_img_bytes = img_bytes;
   }
   const size_t need = (size_t)n_frames * max_kp;
   if (need > h->out_cap || n_frames > h->out_frames) {
-    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+    ORB_HIP_CHECK(wait_own(h));
+    drop_graph(h);
     // one allocation, laid out like the pinned staging (descriptors, keypoints, counts), so that the
     // results come back in one copy
     const size_t cap = std::max(need, h->out_cap), capf = (size_t)std::max(n_frames, h->out_frames);
-    hipFree(h->d_desc);
+    dev_free(h, h->d_desc);
     h->d_desc = nullptr; h->out_cap = 0; h->out_frames = 0;
-    ORB_HIP_CHECK(hipMalloc(&h->d_desc, cap * (32 + sizeof(OrbKeyPoint)) + sizeof(int) * capf));
+    ORB_HIP_CHECK(dev_alloc(h, &h->d_desc, cap * (32 + sizeof(OrbKeyPoint)) + sizeof(int) * capf));
     h->out_cap = cap; h->out_frames = (int)capf;
   }
   // (the layout follows this call's sizes, whatever the allocation's capacity)
@@ -853,6 +923,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   // DMA for the batch (a strided copy from pageable memory is far slower than the kernels).
   if (img_bytes > h->h_img_bytes) {
     ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+    drop_graph(h);
     if (h->h_img) hipHostFree(h->h_img);
     h->h_img = nullptr; h->h_img_bytes = 0;
     ORB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_img), img_bytes, hipHostMallocDefault));
@@ -874,7 +945,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
     const size_t out_bytes_p = need * (sizeof(OrbKeyPoint) + 32) + sizeof(int) * (size_t)n_frames;
     if (out_bytes_p > h->h_out_bytes) {
       ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
-      if (h->h_out) hipHostFree(h->h_out);
+      { drop_graph(h); if (h->h_out) hipHostFree(h->h_out); }
       h->h_out = nullptr; h->h_out_bytes = 0;
       ORB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_out), out_bytes_p, hipHostMallocDefault));
       h->h_out_bytes = out_bytes_p;
@@ -939,7 +1010,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
       ORB_HIP_CHECK(hipStreamWaitEvent(st, h->pipe_ev[2 * p], 0));
       rc = enqueue(h, fn, h->d_img + (size_t)f0 * frame_bytes, row_bytes, frame_bytes, max_kp, h->d_kps + (size_t)f0 * max_kp,
                    h->d_desc + (size_t)f0 * max_kp * 32, h->d_nout + f0, st, f0);
-      if (rc != ORBHIP_OK) { hipDeviceSynchronize(); return rc; }
+      if (rc != ORBHIP_OK) { wait_own(h); return rc; }
       ORB_HIP_CHECK(hipEventRecord(h->pipe_ev[2 * p + 1], st));
       ORB_HIP_CHECK(hipStreamWaitEvent(h->down, h->pipe_ev[2 * p + 1], 0));
       const size_t k0 = (size_t)f0 * max_kp, kn = (size_t)fn * max_kp;
@@ -978,7 +1049,7 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
   const size_t out_bytes = need * (sizeof(OrbKeyPoint) + 32) + sizeof(int) * (size_t)n_frames;
   if (out_bytes > h->h_out_bytes) {
     ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
-    if (h->h_out) hipHostFree(h->h_out);
+    { drop_graph(h); if (h->h_out) hipHostFree(h->h_out); }
     h->h_out = nullptr; h->h_out_bytes = 0;
     ORB_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_out), out_bytes, hipHostMallocDefault));
     h->h_out_bytes = out_bytes;
@@ -993,7 +1064,8 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
     ORB_HIP_CHECK(hipMemcpyAsync(h->h_out, h->d_desc, out_bytes, hipMemcpyDeviceToHost, st));
     return ORBHIP_OK;
   };
-  if (small && !h->profiling) {
+  const bool use_graph = small && !h->profiling;
+  if (use_graph) {
     OrbExtractor::GraphKey key;
     key.n_frames = n_frames; key.rows = rows; key.cols = cols; key.max_kp = max_kp; key.channels = h->channels;
     key.rgb = h->rgb_order; key.fused = h->fused_blur;
@@ -1013,9 +1085,12 @@ int orb_extract_batch(OrbExtractor* h, int n_frames, const uint8_t* images, int 
       h->graph_key = key;
     }
     ORB_HIP_CHECK(hipGraphLaunch(h->graph_exec, st));
+    // (enqueue() ran when the graph was captured, not now: what it notes about the call is noted here)
     h->last_frames = n_frames;
+    h->blur_stale = h->fused_blur;
   } else {
-    rc = device_work(false);
+    // a small batch has only been packed so far (its upload is a node of the graph that is not used here)
+    rc = device_work(small);
     if (rc != ORBHIP_OK) return rc;
   }
   ORB_HIP_CHECK(hipStreamSynchronize(st));
@@ -1059,13 +1134,14 @@ static int copy_level(OrbExtractor* h, const uint8_t* buf, int frame, int level,
   if (!dst) return ORBHIP_OK;
   if (dst_stride < (size_t)w) { set_error("dst_stride too small"); return ORBHIP_ERR_ARG; }
   DeviceGuard g(h->device);
-  ORB_HIP_CHECK(hipDeviceSynchronize());
+  ORB_HIP_CHECK(wait_own(h));
   const uint8_t* src = buf + (size_t)frame * h->plan.slab + L.off +
                        (padded ? (size_t)(kXOff - kEdge) : (size_t)kEdge * L.pitch + kXOff);
-  // one plain copy of the rows as they lie in the slab, then row by row into the caller's array
-  // (a strided copy straight into pageable memory came back incomplete when a profiler was attached)
+  // one plain copy of the rows as they lie in the slab, on the handle's stream, then row by row into
+  // the caller's array
   std::vector<uint8_t> rows((size_t)(hh - 1) * L.pitch + w);
-  ORB_HIP_CHECK(hipMemcpy(rows.data(), src, rows.size(), hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpyAsync(rows.data(), src, rows.size(), hipMemcpyDeviceToHost, h->stream));
+  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
   for (int r = 0; r < hh; r++) memcpy(dst + (size_t)r * dst_stride, rows.data() + (size_t)r * L.pitch, (size_t)w);
   return ORBHIP_OK;
 }
@@ -1080,7 +1156,7 @@ int orb_get_blurred_level(OrbExtractor* h, int frame, int level, uint8_t* dst, s
   if (h && h->have_plan && h->blur_stale && h->last_frames > 0) {
     // the last call blurred patches only: blur the levels of its frames now
     DeviceGuard g(h->device);
-    ORB_HIP_CHECK(hipDeviceSynchronize());
+    ORB_HIP_CHECK(wait_own(h));
     launch_blur(h->d_pyr, h->d_blur, h->plan, h->d_blur_items, (int)h->blur_items.size(), h->taps, h->last_frames,
                 h->stream);
     ORB_HIP_CHECK(hipGetLastError());
@@ -1095,11 +1171,15 @@ static int fetch_points(OrbExtractor* h, const uint32_t* d_arr, int per_frame, i
   int rc = check_frame_level(h, frame, level);
   if (rc != ORBHIP_OK) return rc;
   DeviceGuard g(h->device);
-  ORB_HIP_CHECK(hipDeviceSynchronize());
+  ORB_HIP_CHECK(wait_own(h));
   int n = 0;
-  ORB_HIP_CHECK(hipMemcpy(&n, d_cnt + frame * h->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+  ORB_HIP_CHECK(hipMemcpyAsync(&n, d_cnt + frame * h->nlevels + level, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
   out.resize(n);
-  if (n) ORB_HIP_CHECK(hipMemcpy(out.data(), d_arr + (size_t)frame * per_frame + off, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  if (n) {
+    ORB_HIP_CHECK(hipMemcpyAsync(out.data(), d_arr + (size_t)frame * per_frame + off, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    ORB_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
   return ORBHIP_OK;
 }
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "orb_common.h"
+#include "orb_hostbuf.h"
 
 namespace orbhip {
 hipError_t launch_knn2_mfma(const uint8_t* d_q, int n_q, const uint8_t* d_db, int n_db, int index_base, float ratio,
@@ -174,6 +175,44 @@ hipError_t launch_knn2_merge(int nshards, int nq, size_t shard_stride, const int
                              float ratio, int* ob, int* os, int* oi, uint8_t* oa, hipStream_t st) {
   hipLaunchKernelGGL(knn2_merge_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, nshards, nq, shard_stride, best, second,
                      idx, ratio, ob, os, oi, oa);
+  return hipGetLastError();
+}
+
+// The same merge on the 8-byte records the ranks of a multi-GPU search exchange: per query
+// x = best | second << 16 (distances are at most 256), y = global row (0xFFFFFFFF = none).
+__global__ __launch_bounds__(256) void knn2_pack_kernel(int nq, const int* __restrict__ best, const int* __restrict__ second,
+                                                        const int* __restrict__ idx, uint2* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  out[i] = make_uint2((uint32_t)best[i] | ((uint32_t)second[i] << 16), (uint32_t)idx[i]);
+}
+
+__global__ __launch_bounds__(256) void knn2_merge_packed_kernel(int nshards, int nq, const uint2* __restrict__ rec,
+                                                                float ratio, int* __restrict__ ob, int* __restrict__ os,
+                                                                int* __restrict__ oi, uint8_t* __restrict__ oa) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  int bd = 256, sd = 256, bi = -1;
+  for (int s = 0; s < nshards; s++) {
+    const uint2 r = rec[(size_t)s * nq + i];
+    const int cb = (int)(r.x & 0xFFFFu), cs = (int)(r.x >> 16), ci = (int)r.y;
+    if (ci >= 0 && cb < bd) { sd = min(bd, cs); bd = cb; bi = ci; }
+    else if (ci >= 0) sd = min(sd, cb);
+  }
+  ob[i] = bd; os[i] = sd; oi[i] = bi;
+  if (oa) oa[i] = (uint8_t)(bi >= 0 && (float)bd < __fmul_rn(ratio, (float)sd));
+}
+
+hipError_t launch_knn2_pack(int nq, const int* best, const int* second, const int* idx, void* packed, hipStream_t st) {
+  hipLaunchKernelGGL(knn2_pack_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, nq, best, second, idx,
+                     reinterpret_cast<uint2*>(packed));
+  return hipGetLastError();
+}
+
+hipError_t launch_knn2_merge_packed(int nshards, int nq, const void* packed, float ratio, int* ob, int* os, int* oi,
+                                    uint8_t* oa, hipStream_t st) {
+  hipLaunchKernelGGL(knn2_merge_packed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, nshards, nq,
+                     reinterpret_cast<const uint2*>(packed), ratio, ob, os, oi, oa);
   return hipGetLastError();
 }
 
@@ -858,133 +897,10 @@ size_t stereo_lds_bytes(int rows, int max_r, bool desc_in_lds) {
   return n;
 }
 
-// ---- host helpers -------------------------------------------------------------
-// The host-buffer entry points may be called from several threads at once (the reference calls
-// its matchers from the tracking, mapping and loop-closing threads).  Each call leases a context
-// with a stream of its own and a device arena for its temporaries, so calls neither wait for one
-// another nor for the extractor: nothing here uses the null stream or synchronises the device.
-// Contexts go back to a pool and are reused by whichever thread calls next.
-struct CallCtx {
-  int dev = 0;
-  hipStream_t stream = nullptr;
-  unsigned char* arena = nullptr;
-  size_t cap = 0;   // bytes of the arena
-  size_t want = 0;  // bytes the largest call so far needed
-};
-
-class CtxPool {
- public:
-  CallCtx* acquire(int dev) {
-    CallCtx* c = nullptr;
-    {
-      std::lock_guard<std::mutex> l(m_);
-      auto& fl = free_[dev & 63];
-      if (!fl.empty()) { c = fl.back(); fl.pop_back(); }
-    }
-    if (!c) {
-      c = new CallCtx();
-      c->dev = dev;
-      if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-    }
-    if (c->want > c->cap) {  // grow between calls: nothing of this context is in flight
-      if (c->arena) hipFree(c->arena);
-      c->arena = nullptr; c->cap = 0;
-      const size_t n = c->want + c->want / 4 + 4096;
-      if (hipMalloc(reinterpret_cast<void**>(&c->arena), n) == hipSuccess) c->cap = n;
-    }
-    return c;
-  }
-  void release(CallCtx* c) {
-    std::lock_guard<std::mutex> l(m_);
-    free_[c->dev & 63].push_back(c);
-  }
-
- private:
-  std::mutex m_;
-  std::vector<CallCtx*> free_[64];
-};
-CtxPool g_ctx_pool;
-
-// Device temporaries of one call: bump allocation from the leased arena (blocks that do not fit
-// are allocated on their own and the arena grows before the next call), copies on the call's stream.
-struct DevBuf {
-  CallCtx* ctx = nullptr;
-  size_t used = 0, total = 0;
-  std::vector<void*> extra;
-  DevBuf() {
-    int dev = 0;
-    hipGetDevice(&dev);
-    ctx = g_ctx_pool.acquire(dev);
-  }
-  ~DevBuf() {
-    if (!ctx) return;
-    if (!extra.empty()) {
-      hipStreamSynchronize(ctx->stream);
-      for (void* p : extra) hipFree(p);
-    }
-    ctx->want = std::max(ctx->want, total);
-    g_ctx_pool.release(ctx);
-  }
-  hipStream_t stream() const { return ctx ? ctx->stream : nullptr; }
-  template <typename T, typename U>
-  int up(const T* host, size_t n, U** out) {
-    static_assert(sizeof(T) == sizeof(U), "element size mismatch");
-    *out = nullptr;
-    if (!ctx) { set_error("could not create a stream"); return ORBHIP_ERR_HIP; }
-    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
-    void* d = nullptr;
-    total += bytes;
-    if (used + bytes <= ctx->cap) {
-      d = ctx->arena + used;
-      used += bytes;
-    } else {
-      hipError_t e = hipMalloc(&d, bytes);
-      if (e != hipSuccess) return hip_fail(e, "hipMalloc");
-      extra.push_back(d);
-    }
-    if (host && n) {
-      hipError_t e = hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
-      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync H2D");
-    }
-    *out = reinterpret_cast<U*>(d);
-    return ORBHIP_OK;
-  }
-  // results back to the host; valid after sync()
-  template <typename T>
-  int down(T* host, const T* dev, size_t n) {
-    if (!n) return ORBHIP_OK;
-    hipError_t e = hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync D2H");
-    return ORBHIP_OK;
-  }
-  int sync() {
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
-    return ORBHIP_OK;
-  }
-};
-
-struct DevSel {
-  int prev = -1;
-  explicit DevSel(int dev) { hipGetDevice(&prev); if (prev != dev) hipSetDevice(dev); else prev = -1; }
-  ~DevSel() { if (prev >= 0) hipSetDevice(prev); }
-};
-
-#define UP(buf, host, n, out)                         \
-  do {                                                \
-    int rc__ = (buf).up((host), (size_t)(n), &(out)); \
-    if (rc__ != ORBHIP_OK) return rc__;               \
-  } while (0)
-#define DOWN(buf, host, dev, n)                               \
-  do {                                                        \
-    int rc__ = (buf).down((host), (dev), (size_t)(n));        \
-    if (rc__ != ORBHIP_OK) return rc__;                       \
-  } while (0)
-#define SYNC(buf)                       \
-  do {                                  \
-    int rc__ = (buf).sync();            \
-    if (rc__ != ORBHIP_OK) return rc__; \
-  } while (0)
+CtxPool& ctx_pool() {
+  static CtxPool pool;
+  return pool;
+}
 
 constexpr size_t kScratchPerQuery = sizeof(uint2) * MK + sizeof(int) * 3 + sizeof(float4);
 
@@ -1145,6 +1061,28 @@ int orb_knn2_merge_device(int device_id, int n_shards, int n_q, const int* d_bes
   DevSel g(device_id);
   ORB_HIP_CHECK(launch_knn2_merge(n_shards, n_q, (size_t)n_q, d_best, d_second, d_idx, ratio, d_out_best, d_out_second,
                                   d_out_idx, d_out_accept, (hipStream_t)stream));
+  return ORBHIP_OK;
+}
+
+int orb_knn2_pack_device(int device_id, int n_q, const int* d_best, const int* d_second, const int* d_idx,
+                         void* d_packed, void* stream) {
+  if (n_q <= 0) return ORBHIP_OK;
+  if (!d_best || !d_second || !d_idx || !d_packed) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if ((uintptr_t)d_packed & 7) { set_error("packed records must be 8-byte aligned"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  ORB_HIP_CHECK(launch_knn2_pack(n_q, d_best, d_second, d_idx, d_packed, (hipStream_t)stream));
+  return ORBHIP_OK;
+}
+
+int orb_knn2_merge_packed_device(int device_id, int n_shards, int n_q, const void* d_packed, float ratio,
+                                 int* d_out_best, int* d_out_second, int* d_out_idx, uint8_t* d_out_accept,
+                                 void* stream) {
+  if (n_q <= 0) return ORBHIP_OK;
+  if (n_shards < 1 || !d_packed || !d_out_best || !d_out_second || !d_out_idx) { set_error("null argument"); return ORBHIP_ERR_ARG; }
+  if ((uintptr_t)d_packed & 7) { set_error("packed records must be 8-byte aligned"); return ORBHIP_ERR_ARG; }
+  DevSel g(device_id);
+  ORB_HIP_CHECK(launch_knn2_merge_packed(n_shards, n_q, d_packed, ratio, d_out_best, d_out_second, d_out_idx,
+                                         d_out_accept, (hipStream_t)stream));
   return ORBHIP_OK;
 }
 

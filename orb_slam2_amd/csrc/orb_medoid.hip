@@ -9,6 +9,7 @@
 // k-th smallest of the 64 distances is found by bisecting the value range with ballots.
 // Larger points take a workgroup each and a 257-bin histogram in LDS.
 #include "orb_common.h"
+#include "orb_hostbuf.h"
 
 #include <vector>
 
@@ -123,38 +124,34 @@ extern "C" int orb_distinctive_descriptors(int device_id, int n_points, const in
   const int total = start[n_points];
   if (total == 0) return ORBHIP_OK;
   if (!desc) { set_error("null descriptors"); return ORBHIP_ERR_ARG; }
-  int prev = -1;
-  hipGetDevice(&prev);
-  if (prev != device_id) ORB_HIP_CHECK(hipSetDevice(device_id));
+  // a leased stream and arena, like the matchers: MapPoint::ComputeDistinctiveDescriptors runs on the
+  // mapping thread beside the tracking thread's calls and must not wait for them
+  DevSel g(device_id);
+  DevBuf buf;
   int *d_start = nullptr, *d_sel = nullptr, *d_out = nullptr;
   uint8_t* d_desc = nullptr;
   const int nsel = (int)(small.size() + large.size());
   std::vector<int> sel(small);
   sel.insert(sel.end(), large.begin(), large.end());
   std::vector<int> out(2 * (size_t)n_points, -1);
-  hipError_t e = hipMalloc(&d_start, sizeof(int) * ((size_t)n_points + 1));
-  if (e == hipSuccess) e = hipMalloc(&d_sel, sizeof(int) * (size_t)nsel);
-  if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(int) * 2 * (size_t)n_points);
-  if (e == hipSuccess) e = hipMalloc(&d_desc, (size_t)32 * total);
-  if (e == hipSuccess) e = hipMemcpy(d_start, start, sizeof(int) * ((size_t)n_points + 1), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_sel, sel.data(), sizeof(int) * (size_t)nsel, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_desc, desc, (size_t)32 * total, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(d_out, 0xFF, sizeof(int) * 2 * (size_t)n_points);
-  if (e == hipSuccess && !small.empty()) {
+  UP(buf, start, (size_t)n_points + 1, d_start);
+  UP(buf, sel.data(), (size_t)nsel, d_sel);
+  UP(buf, desc, (size_t)32 * total, d_desc);
+  UP(buf, (const int*)nullptr, 2 * (size_t)n_points, d_out);
+  ORB_HIP_CHECK(hipMemsetAsync(d_out, 0xFF, sizeof(int) * 2 * (size_t)n_points, buf.stream()));
+  if (!small.empty()) {
     hipLaunchKernelGGL(medoid_small_kernel, dim3(((unsigned)small.size() + MD_WAVES - 1) / MD_WAVES), dim3(64 * MD_WAVES), 0,
-                       nullptr, (int)small.size(), d_sel, d_start, reinterpret_cast<const uint4*>(d_desc), d_out,
+                       buf.stream(), (int)small.size(), d_sel, d_start, reinterpret_cast<const uint4*>(d_desc), d_out,
                        d_out + n_points);
-    e = hipGetLastError();
+    ORB_HIP_CHECK(hipGetLastError());
   }
-  if (e == hipSuccess && !large.empty()) {
-    hipLaunchKernelGGL(medoid_large_kernel, dim3((unsigned)large.size()), dim3(256), 0, nullptr, (int)large.size(),
+  if (!large.empty()) {
+    hipLaunchKernelGGL(medoid_large_kernel, dim3((unsigned)large.size()), dim3(256), 0, buf.stream(), (int)large.size(),
                        d_sel + small.size(), d_start, reinterpret_cast<const uint4*>(d_desc), d_out, d_out + n_points);
-    e = hipGetLastError();
+    ORB_HIP_CHECK(hipGetLastError());
   }
-  if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, sizeof(int) * 2 * (size_t)n_points, hipMemcpyDeviceToHost);
-  hipFree(d_start); hipFree(d_sel); hipFree(d_out); hipFree(d_desc);
-  if (prev >= 0 && prev != device_id) hipSetDevice(prev);
-  if (e != hipSuccess) return hip_fail(e, "orb_distinctive_descriptors");
+  DOWN(buf, out.data(), d_out, 2 * (size_t)n_points);
+  SYNC(buf);
   for (int p = 0; p < n_points; p++) {
     best_idx[p] = out[p];
     if (best_median) best_median[p] = out[(size_t)n_points + p];

@@ -7,6 +7,7 @@
 // operations (the file is built without multiply-add contraction), so its doubles are the ones
 // a C restatement produces.
 #include "orb_common.h"
+#include "orb_hostbuf.h"
 
 #include <vector>
 
@@ -95,21 +96,15 @@ int orb_undistort_points(int device_id, int n, const float* xy, OrbCamera cam, f
   if (n <= 0) return ORBHIP_OK;
   if (!xy || !xy_un) { set_error("null argument"); return ORBHIP_ERR_ARG; }
   if (!cam_ok(cam)) { set_error("focal length is zero"); return ORBHIP_ERR_ARG; }
-  int prev = -1;
-  hipGetDevice(&prev);
-  if (prev != device_id) ORB_HIP_CHECK(hipSetDevice(device_id));
+  DevSel g(device_id);
+  DevBuf buf;  // a stream and arena of the call's own
   float2 *d_in = nullptr, *d_out = nullptr;
-  hipError_t e = hipMalloc(&d_in, sizeof(float2) * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(float2) * (size_t)n);
-  if (e == hipSuccess) e = hipMemcpy(d_in, xy, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(undistort_xy_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, d_in, make_cam(cam), d_out);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpy(xy_un, d_out, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost);
-  hipFree(d_in); hipFree(d_out);
-  if (prev >= 0 && prev != device_id) hipSetDevice(prev);
-  if (e != hipSuccess) return hip_fail(e, "orb_undistort_points");
+  UP(buf, reinterpret_cast<const float2*>(xy), (size_t)n, d_in);
+  UP(buf, (const float2*)nullptr, (size_t)n, d_out);
+  hipLaunchKernelGGL(undistort_xy_kernel, dim3((n + 255) / 256), dim3(256), 0, buf.stream(), n, d_in, make_cam(cam), d_out);
+  ORB_HIP_CHECK(hipGetLastError());
+  DOWN(buf, reinterpret_cast<float2*>(xy_un), d_out, (size_t)n);
+  SYNC(buf);
   return ORBHIP_OK;
 }
 

@@ -16,25 +16,64 @@ def shard_bounds(n_rows, world, rank):
     return n_rows * rank // world, n_rows * (rank + 1) // world
 
 
-def knn2_sharded(local_search, merge, n_q, device, world, group=None):
+def pack_records(res):
+    """[3, n_q] int32 (best, second, global index) -> [n_q, 2] int32: the 8-byte records the ranks
+    exchange, word 0 = best | second << 16 (distances are at most 256), word 1 = index (-1 = none).
+    Plain tensor arithmetic, so the same code serves host (gloo) and device tensors."""
+    return torch.stack([res[0] | (res[1] << 16), res[2]], dim=1).contiguous()
+
+
+def unpack_records(rec):
+    """[world, n_q, 2] int32 records -> [3, world, n_q] int32 (best, second, index)."""
+    w0, w1 = rec[..., 0], rec[..., 1]
+    return torch.stack([w0 & 0xFFFF, (w0 >> 16) & 0xFFFF, w1], dim=0).contiguous()
+
+
+def knn2_sharded(local_search, merge, n_q, device, world, group=None, codec="packed8", merge_packed=None,
+                 timings=None):
     """local_search() -> int32 tensor [3, n_q] (best, second, global index) for this rank's
     shard; merge(g) with g int32 [3, world, n_q] -> (int32 [3, n_q], uint8 [n_q] accept).
-    Returns the merged tensors (identical on every rank)."""
+    Returns the merged tensors (identical on every rank).
+
+    codec: what one rank sends per query - "packed8": one 8-byte record (pack_records), the default;
+    "int32x3": the three int32 values as they are (12 bytes).  Both give the same result.
+    merge_packed(rec) with rec int32 [world, n_q, 2], if given, merges the records directly (the HIP
+    kernel does); otherwise they are unpacked and handed to merge.
+    timings: a dict that receives "scan_s" and "exchange_s" (host clock; the caller synchronises the
+    device in local_search / merge if it wants device time)."""
+    import time
+    t0 = time.perf_counter()
     res = local_search()
     assert res.shape == (3, n_q) and res.dtype == torch.int32
+    if timings is not None:
+        if res.is_cuda:
+            torch.cuda.synchronize(res.device)
+        timings["scan_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+    send = pack_records(res) if codec == "packed8" else res.contiguous()
     if world > 1:
-        if res.is_cuda and dist.get_backend(group) == "gloo":
+        # (the ranks' blocks are concatenated along the first dimension: the form every backend takes)
+        shape = (world * send.shape[0],) + tuple(send.shape[1:])
+        if send.is_cuda and dist.get_backend(group) == "gloo":
             # gloo carries host tensors only: stage through the host (CPU rehearsals of the GPU path)
-            gathered = torch.empty((world * 3, n_q), dtype=torch.int32)
-            dist.all_gather_into_tensor(gathered, res.cpu().contiguous(), group=group)
+            gathered = torch.empty(shape, dtype=torch.int32)
+            dist.all_gather_into_tensor(gathered, send.cpu(), group=group)
             gathered = gathered.to(device)
         else:
-            gathered = torch.empty((world * 3, n_q), dtype=torch.int32, device=device)
-            dist.all_gather_into_tensor(gathered, res.contiguous(), group=group)
-        g = gathered.view(world, 3, n_q).permute(1, 0, 2).contiguous()
+            gathered = torch.empty(shape, dtype=torch.int32, device=device)
+            dist.all_gather_into_tensor(gathered, send, group=group)
+        gathered = gathered.view((world,) + tuple(send.shape))
     else:
-        g = res.reshape(3, 1, n_q)
-    return merge(g)
+        gathered = send.unsqueeze(0)
+    if codec == "packed8":
+        out = merge_packed(gathered) if merge_packed is not None else merge(unpack_records(gathered))
+    else:
+        out = merge(gathered.permute(1, 0, 2).contiguous())
+    if timings is not None:
+        if out[0].is_cuda:
+            torch.cuda.synchronize(out[0].device)
+        timings["exchange_s"] = time.perf_counter() - t0
+    return out
 
 
 def hip_local_search(d_q, d_db_shard, index_base, ratio, device_index, stream=0):
@@ -63,6 +102,21 @@ def hip_merge(ratio, device_index, stream=0):
         _lib.check(L.orb_knn2_merge_device(device_index, world, n_q, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
                                            ratio, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                            acc.data_ptr(), stream))
+        return out, acc
+    return run
+
+
+def hip_merge_packed(ratio, device_index, stream=0):
+    """Closure running orb_knn2_merge_packed_device on gathered 8-byte records [world, n_q, 2]."""
+    from . import _lib
+    L = _lib.lib()
+
+    def run(rec):
+        world, n_q, _ = rec.shape
+        out = torch.empty((3, n_q), dtype=torch.int32, device=rec.device)
+        acc = torch.empty(n_q, dtype=torch.uint8, device=rec.device)
+        _lib.check(L.orb_knn2_merge_packed_device(device_index, world, n_q, rec.data_ptr(), ratio, out[0].data_ptr(),
+                                                  out[1].data_ptr(), out[2].data_ptr(), acc.data_ptr(), stream))
         return out, acc
     return run
 
@@ -113,3 +167,17 @@ class RcclKnn:
                                                 index_base, ratio, out[0].data_ptr(), out[1].data_ptr(),
                                                 out[2].data_ptr(), acc.data_ptr(), stream))
         return out, acc
+
+    def info(self):
+        """(rank, world, ranks the communicator itself reports)"""
+        import ctypes as C
+        r, w, n = C.c_int(), C.c_int(), C.c_int()
+        self._lib.check(self.L.orb_knn2_comm_info(self._h, C.byref(r), C.byref(w), C.byref(n)))
+        return r.value, w.value, n.value
+
+    def times(self):
+        """(scan_ms, exchange_ms) of the last search, by HIP events on its stream"""
+        import ctypes as C
+        a, b = C.c_float(), C.c_float()
+        self._lib.check(self.L.orb_knn2_sharded_times(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -616,3 +616,94 @@ def test_opencv_release_switch(oracle, major, minor):
         assert not np.array_equal(d.blurred_level(0), ex.blurred_level(0))
     with pytest.raises(OrbHipError):
         ex.set_opencv_compat(2, 4)
+
+
+def test_profiled_small_host_calls_upload_their_images(oracle):
+    """With stage timing on, a host-buffer call of a few frames takes the plain launch sequence
+    instead of the captured graph; it must still upload its own images: two different images one
+    after the other on one handle, each equal to the unprofiled result, and stage times come back."""
+    import ctypes as C
+    from orb_slam2_amd import ORBextractor, _lib
+    from orb_slam2_amd.synth import synth_image
+    L = _lib.lib()
+    imgs = [synth_image(240, 320, seed=s) for s in (31, 32)]
+    plain = ORBextractor(500, 1.2, 6, 20, 7)
+    want = [plain(im) for im in imgs]
+    assert not np.array_equal(want[0][0], want[1][0])
+    ex = ORBextractor(500, 1.2, 6, 20, 7)
+    _lib.check(L.orb_extractor_set_profiling(ex._h, 1))
+    for im, (wk, wd) in zip(imgs, want):   # the very first call on the handle is profiled too
+        k, d = ex(im)
+        assert np.array_equal(k, wk) and np.array_equal(d, wd)
+    ms = np.zeros(5, np.float32)
+    assert _lib.check(L.orb_extractor_stage_times(ex._h, ms.ctypes.data)) == 5 and ms.sum() > 0
+    _lib.check(L.orb_extractor_set_profiling(ex._h, 0))
+    # back on the graph path, and profiled again after it: still each call's own image
+    for im, (wk, wd) in list(zip(imgs, want))[::-1]:
+        k, d = ex(im)
+        assert np.array_equal(k, wk) and np.array_equal(d, wd)
+    _lib.check(L.orb_extractor_set_profiling(ex._h, 1))
+    k, d = ex(imgs[1])
+    assert np.array_equal(k, want[1][0]) and np.array_equal(d, want[1][1])
+
+
+def test_blurred_level_follows_the_last_call_on_a_reused_handle(oracle):
+    """The blurred levels are made on demand after a call with the blur fused into the descriptor
+    kernel.  A second image of the same size on the same handle replays the captured graph; the
+    blurred level asked for afterwards must be the second image's, not the first one's."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd.synth import synth_image
+    a, b = synth_image(240, 320, seed=41), synth_image(240, 320, seed=42)
+    ex = ORBextractor(500, 1.2, 6, 20, 7)
+    ref = oracle.Extractor(500, 1.2, 6, 20, 7)
+    ex(a)
+    ref(a)
+    assert np.array_equal(ex.blurred_level(0), ref.blurred_level(0))
+    for img in (b, a, b):            # replays of the same graph
+        ex(img)
+        ref(img)
+        for l in (0, 3):
+            rb = ref.blurred_level(l)
+            if rb is not None:
+                assert np.array_equal(ex.blurred_level(l), rb), l
+    # a batch of three after single frames (another graph), frame 2 asked for
+    ex.extract_batch(np.stack([a, b, a]))
+    ref(a)
+    assert np.array_equal(ex.blurred_level(0, frame=2), ref.blurred_level(0))
+    ex.extract_batch(np.stack([a, a, b]))
+    ref(b)
+    assert np.array_equal(ex.blurred_level(0, frame=2), ref.blurred_level(0))
+
+
+def test_handle_changes_size_between_host_and_device_calls(oracle):
+    """One handle through image sizes and both call forms in turn (every change reallocates the
+    handle's buffers on its own stream and drops the captured graph): results stay those of a fresh
+    handle."""
+    import torch
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd._lib import KP_DTYPE
+    from orb_slam2_amd.synth import synth_image
+    dev = torch.device("cuda", 0)
+    ex = ORBextractor(400, 1.2, 5, 20, 7)
+    side = torch.cuda.Stream(device=dev)
+    for it, (rows, cols) in enumerate([(240, 320), (200, 260), (240, 320), (300, 500), (200, 260)]):
+        img = synth_image(rows, cols, seed=50 + it)
+        wk, wd = ORBextractor(400, 1.2, 5, 20, 7)(img)
+        if it % 2 == 0:
+            k, d = ex(img)
+        else:
+            cap = ex.max_keypoints(rows, cols)
+            d_img = torch.from_numpy(img).to(dev)
+            d_k = torch.zeros((1, cap, 6), dtype=torch.float32, device=dev)
+            d_d = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+            d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            ex.set_input_format(1)
+            ex.extract_batch_device(d_img.data_ptr(), 1, rows, cols, d_k.data_ptr(), d_d.data_ptr(), d_n.data_ptr(), cap,
+                                    stream=side.cuda_stream)
+            lvl = ex.pyramid_level(1)        # waits for the call on the side stream, not for the device
+            assert lvl.shape[0] > 0
+            n = int(d_n.item())
+            k = d_k[0, :n].cpu().numpy().view(np.uint8).reshape(n, 24).copy().view(KP_DTYPE)[:, 0]
+            d = d_d[0, :n].cpu().numpy()
+        assert np.array_equal(k, wk) and np.array_equal(d, wd), it
