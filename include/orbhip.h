@@ -237,8 +237,16 @@ int orb_search_by_projection_frames(
  * last-frame records supply mvKeys[i].octave and mvKeysUn[i].angle).  Pair p uses
  * d_last_* + p*max_last and d_cur_* + p*max_cur.  scale_factors is a HOST array.
  * d_scratch must hold orb_match_scratch_bytes(n_pairs, max_last) bytes.  Enqueued on
- * `stream`, not waited for; allocates nothing. */
+ * `stream`, not waited for; allocates nothing.
+ * Size limits of the matchers: up to about 9000 train keypoints per frame (current-frame
+ * keypoints here; about 7300 for orb_search_for_initialization) the keypoints' grid lives in
+ * on-chip memory.  Larger frames, up to 65535 keypoints, take a second form of the kernel that
+ * keeps part of it in global memory: the host-buffer entry points do that by themselves, the
+ * device form needs d_scratch sized with orb_match_scratch_bytes_for(n_pairs, max_last, max_cur)
+ * (equal to orb_match_scratch_bytes while max_cur fits on chip) and returns ORBHIP_ERR_CAPACITY
+ * otherwise; the allocation-free form below is limited to frames that fit on chip. */
 size_t orb_match_scratch_bytes(int n_pairs, int max_queries);
+size_t orb_match_scratch_bytes_for(int n_pairs, int max_last, int max_cur);
 int orb_search_by_projection_frames_device(
     int device_id, int n_pairs, int max_last, int max_cur, const float* d_tcw, float fx, float fy,
     float cx, float cy, OrbFrameBounds bounds, const float* scale_factors, int nlevels,

@@ -257,6 +257,9 @@ struct MatchArgs {
   float ex, ey, th, nnratio;
   // scratch, per pair slices of max_q
   uint2* lists; int* q_ntot; float4* q_geo; int* q_slot; int* q_bin;
+  // frames with more train keypoints than fit in LDS (match_kernel<MODE, true>): per pair a block of
+  // big_stride bytes that holds the keypoint coordinates, grid items and claim / owner words
+  unsigned char* big; size_t big_stride;
   // outputs
   int* out_match; int* n_matches;
 };
@@ -293,6 +296,20 @@ struct MatchShared {
   uint2* lists;          // max_q * MK ranked candidates (LDS if it fits, else global scratch)
   int* ntot;             // max_q: candidates seen (bit 30: the query's map point has observations), -1 = inactive
 };
+
+// Words of the replay that several lanes of the replaying wavefront write and read in turn (claims,
+// owners).  In LDS plain accesses do; in global memory (BIG) a plain load may be served by the
+// vector cache while the atomic it follows was performed in L2, so loads and stores go to L2.
+template <bool BIG>
+__device__ __forceinline__ int word_load(const int* p) {
+  if constexpr (BIG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool BIG>
+__device__ __forceinline__ void word_store(int* p, int v) {
+  if constexpr (BIG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
 
 // Frame::GetFeaturesInArea (reference src/Frame.cc:371-449) fused with the best /
 // second scan of the caller.  Visits candidates in the reference's order
@@ -419,7 +436,7 @@ __device__ __forceinline__ int rot_bin(float rot) {
   return bin;
 }
 
-template <int MODE>
+template <int MODE, bool BIG>
 __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_hist[HISTO_LENGTH];
@@ -430,14 +447,27 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   {
     unsigned char* p = smem;
     S.start = reinterpret_cast<int*>(p); p += sizeof(int) * (GRID_COLS * GRID_ROWS + 4);
-    S.kx = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
-    S.ky = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
-    S.items = reinterpret_cast<unsigned short*>(p); p += sizeof(unsigned short) * ((A.max_t + 1) & ~1);
-    S.koct = p; p += (A.max_t + 3) & ~3;
-    S.occ = p; p += (A.max_t + 3) & ~3;
-    S.claim = reinterpret_cast<int*>(p); p += sizeof(int) * A.max_t;
-    S.owner = reinterpret_cast<int*>(p);
-    if (MODE == MODE_INIT) p += sizeof(int) * A.max_t;
+    if constexpr (BIG) {
+      // LDS keeps the grid's offsets and the two byte arrays every candidate test reads; the rest
+      // lives in the pair's block of global scratch (laid out by match_big_stride)
+      S.koct = p; p += (A.max_t + 3) & ~3;
+      S.occ = p; p += (A.max_t + 3) & ~3;
+      unsigned char* g = A.big + (size_t)pair * A.big_stride;
+      S.kx = reinterpret_cast<float*>(g); g += sizeof(float) * A.max_t;
+      S.ky = reinterpret_cast<float*>(g); g += sizeof(float) * A.max_t;
+      S.claim = reinterpret_cast<int*>(g); g += sizeof(int) * A.max_t;
+      S.owner = reinterpret_cast<int*>(g); g += sizeof(int) * A.max_t;
+      S.items = reinterpret_cast<unsigned short*>(g);
+    } else {
+      S.kx = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
+      S.ky = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
+      S.items = reinterpret_cast<unsigned short*>(p); p += sizeof(unsigned short) * ((A.max_t + 1) & ~1);
+      S.koct = p; p += (A.max_t + 3) & ~3;
+      S.occ = p; p += (A.max_t + 3) & ~3;
+      S.claim = reinterpret_cast<int*>(p); p += sizeof(int) * A.max_t;
+      S.owner = reinterpret_cast<int*>(p);
+      if (MODE == MODE_INIT) p += sizeof(int) * A.max_t;
+    }
     p = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
     if (A.desc_in_lds) {
       S.tdesc = reinterpret_cast<const uint4*>(p); p += 32 * (size_t)A.max_t;
@@ -693,15 +723,19 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
         const unsigned long long pending = __ballot(!resolved);
         if (pending == 0) break;
         // claim[s] = lowest pending lane that would occupy s
-        if (occupy) atomicMin(&S.claim[s1], lane);
+        if (occupy) {
+          const int before = atomicMin(&S.claim[s1], lane);
+          // (global claims: the loads below must not overtake the atomics, so their answers are waited for)
+          if constexpr (BIG) asm volatile("" ::"v"(before));
+        }
         __builtin_amdgcn_wave_barrier();
         bool conflict = false;
         if (!resolved && s1 >= 0) {
-          conflict = S.claim[s1] < lane;
-          if ((MODE == MODE_MAPPOINTS || MODE == MODE_BOW || MODE == MODE_INIT) && s2 >= 0) conflict = conflict || S.claim[s2] < lane;
+          conflict = word_load<BIG>(&S.claim[s1]) < lane;
+          if ((MODE == MODE_MAPPOINTS || MODE == MODE_BOW || MODE == MODE_INIT) && s2 >= 0) conflict = conflict || word_load<BIG>(&S.claim[s2]) < lane;
         }
         __builtin_amdgcn_wave_barrier();
-        if (occupy) S.claim[s1] = 0x7FFFFFFF;
+        if (occupy) word_store<BIG>(&S.claim[s1], 0x7FFFFFFF);
         const unsigned long long cm = __ballot(conflict);
         const int first_conf = cm ? (__ffsll((long long)cm) - 1) : 64;
         if (!resolved && lane < first_conf) {
@@ -709,9 +743,9 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
           if (accept) {
             if constexpr (MODE == MODE_INIT) {
               // a keypoint matched before goes to the new query (reference :619-628)
-              const int prev = S.owner[s1];
+              const int prev = word_load<BIG>(&S.owner[s1]);
               if (prev >= 0) { out_match[prev] = -1; atomicSub(&s_nm, 1); }
-              S.owner[s1] = i;
+              word_store<BIG>(&S.owner[s1], i);
               S.occ[s1] = (unsigned char)(d1 + 1);
               out_match[i] = s1;
             } else if (occupy) {
@@ -788,6 +822,14 @@ size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds, bool desc_in_lds
   if (desc_in_lds) n += 32 * (size_t)max_t;
   if (owner) n += sizeof(int) * (size_t)max_t;
   return n;
+}
+
+// LDS of match_kernel<MODE, true> and the size of its per-pair block of global scratch
+size_t match_big_lds_bytes(int max_t) {
+  return sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + 2 * (size_t)((max_t + 3) & ~3) + 32;
+}
+size_t match_big_stride(int max_t) {
+  return ((4 * sizeof(int) + sizeof(unsigned short)) * (size_t)max_t + 2 + 255) & ~(size_t)255;
 }
 
 // ---------------------------------------------------------------------------
@@ -913,29 +955,49 @@ void carve_scratch(MatchArgs& A, void* scratch, size_t nq) {
   A.q_bin = reinterpret_cast<int*>(p);
 }
 
+constexpr size_t kMatchLdsLimit = 156 * 1024;
+
+// true if the train side does not fit match_kernel's LDS-resident form (about 9000 keypoints; 7300
+// for SearchForInitialization, which also keeps an owner per keypoint) and the call needs the
+// per-pair block of global scratch of the large form
+template <int MODE>
+bool match_needs_big(int max_t, int max_q) {
+  return match_lds_bytes(max_t, max_q, false, false, MODE == MODE_INIT) > kMatchLdsLimit;
+}
+
+template <int MODE, bool BIG>
+int launch_match_as(const MatchArgs& A, int n_pairs, size_t lds, hipStream_t st) {
+  static std::atomic<bool> raised[64];  // per device: raise the function's dynamic LDS limit once
+  int dev = 0;
+  ORB_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
+    ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_kernel<MODE, BIG>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsLimit));
+    if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((match_kernel<MODE, BIG>), dim3(n_pairs), dim3(M_THREADS), lds, st, A);
+  ORB_HIP_CHECK(hipGetLastError());
+  return ORBHIP_OK;
+}
+
 template <int MODE>
 int launch_match(const MatchArgs& A0, int n_pairs, hipStream_t st) {
   MatchArgs A = A0;
   if (!A.keyframe_origin) { A.q_min_x = A.b.min_x; A.q_min_y = A.b.min_y; }
   else { A.q_min_x = (float)(int)A.b.min_x; A.q_min_y = (float)(int)A.b.min_y; }  // KeyFrame::mnMinX / mnMinY are const int
-  constexpr size_t kLdsLimit = 156 * 1024;
-  // descriptors first (every candidate reads them), then the ranked lists if there is room
   constexpr bool own = MODE == MODE_INIT;
-  A.desc_in_lds = match_lds_bytes(A.max_t, A.max_q, false, true, own) <= kLdsLimit;
-  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, A.desc_in_lds != 0, own) <= kLdsLimit;
-  const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0, own);
-  if (lds > kLdsLimit) { set_error("too many train keypoints for the LDS-resident grid (limit about 9000)"); return ORBHIP_ERR_UNSUPPORTED; }
-  static std::atomic<bool> raised[64];  // per device: raise the function's dynamic LDS limit once
-  int dev = 0;
-  ORB_HIP_CHECK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
-    ORB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_kernel<MODE>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
+  if (match_needs_big<MODE>(A.max_t, A.max_q)) {
+    if (!A.big) { set_error("too many train keypoints for the on-chip grid and no scratch for the large form was given"); return ORBHIP_ERR_CAPACITY; }
+    A.desc_in_lds = 0; A.lists_in_lds = 0;
+    const size_t lds = match_big_lds_bytes(A.max_t);
+    if (lds > kMatchLdsLimit) { set_error("too many train keypoints (limit 65535)"); return ORBHIP_ERR_UNSUPPORTED; }
+    return launch_match_as<MODE, true>(A, n_pairs, lds, st);
   }
-  hipLaunchKernelGGL(match_kernel<MODE>, dim3(n_pairs), dim3(M_THREADS), lds, st, A);
-  ORB_HIP_CHECK(hipGetLastError());
-  return ORBHIP_OK;
+  // descriptors first (every candidate reads them), then the ranked lists if there is room
+  A.desc_in_lds = match_lds_bytes(A.max_t, A.max_q, false, true, own) <= kMatchLdsLimit;
+  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, A.desc_in_lds != 0, own) <= kMatchLdsLimit;
+  const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0, own);
+  return launch_match_as<MODE, false>(A, n_pairs, lds, st);
 }
 
 template <int MODE>
@@ -944,6 +1006,10 @@ int run_match(MatchArgs& A, int n_pairs, DevBuf& buf) {
   unsigned char* scratch;
   UP(buf, (const unsigned char*)nullptr, nq * kScratchPerQuery + 64, scratch);
   carve_scratch(A, scratch, nq);
+  if (match_needs_big<MODE>(A.max_t, A.max_q)) {
+    A.big_stride = match_big_stride(A.max_t);
+    UP(buf, (const unsigned char*)nullptr, A.big_stride * (size_t)n_pairs, A.big);
+  }
   if (A.ts == 0) A.ts = 1;
   if (A.qs == 0) A.qs = 1;
   return launch_match<MODE>(A, n_pairs, buf.stream());  // the caller copies the results back and waits
@@ -1149,6 +1215,12 @@ size_t orb_match_scratch_bytes(int n_pairs, int max_queries) {
   return (size_t)n_pairs * max_queries * kScratchPerQuery + 64;
 }
 
+size_t orb_match_scratch_bytes_for(int n_pairs, int max_last, int max_cur) {
+  size_t n = (orb_match_scratch_bytes(n_pairs, max_last) + 255) & ~(size_t)255;
+  if (n_pairs > 0 && max_cur > 0 && match_needs_big<MODE_FRAMES>(max_cur, max_last)) n += match_big_stride(max_cur) * (size_t)n_pairs;
+  return n;
+}
+
 // Shared body of the two device-record forms below: argument checks, the MatchArgs of
 // MODE_FRAMES on OrbKeyPoint records, launch on the caller's stream.  `scratch` is a device
 // address holding orb_match_scratch_bytes(n_pairs, max_last) bytes.
@@ -1157,8 +1229,8 @@ static int frames_device_launch(int n_pairs, int max_last, int max_cur, const fl
                                 const int* d_n_last, const OrbKeyPoint* d_last_kps, const int* d_last_mp_obs,
                                 const float* d_last_xw, const uint8_t* d_last_mp_desc, const int* d_n_cur,
                                 const OrbKeyPoint* d_cur_kps, const uint8_t* d_cur_desc, const int* d_cur_obs, float th,
-                                int check_orientation, void* scratch, int* d_cur_match, int* d_n_matches,
-                                hipStream_t stream) {
+                                int check_orientation, void* scratch, size_t scratch_bytes, int* d_cur_match,
+                                int* d_n_matches, hipStream_t stream) {
   if (((uintptr_t)d_last_mp_desc | (uintptr_t)d_cur_desc | (uintptr_t)scratch) & 15) { set_error("descriptor and scratch arrays must be 16-byte aligned"); return ORBHIP_ERR_ARG; }
   MatchArgs A{};
   A.max_q = max_last; A.max_t = max_cur; A.nlevels = nlevels; A.check_ori = check_orientation;
@@ -1174,6 +1246,17 @@ static int frames_device_launch(int n_pairs, int max_last, int max_cur, const fl
   A.t_desc = d_cur_desc; A.t_obs = d_cur_obs;
   A.out_match = d_cur_match; A.n_matches = d_n_matches;
   carve_scratch(A, scratch, (size_t)n_pairs * max_last);
+  if (match_needs_big<MODE_FRAMES>(max_cur, max_last)) {
+    // more current-frame keypoints than the on-chip grid holds: the large form's block lies behind
+    // the per-query arrays, if the caller sized the scratch with orb_match_scratch_bytes_for
+    if (scratch_bytes < orb_match_scratch_bytes_for(n_pairs, max_last, max_cur)) {
+      set_error("max_cur = " + std::to_string(max_cur) + " keypoints do not fit the on-chip grid (about 9000): size the "
+                "scratch with orb_match_scratch_bytes_for(n_pairs, max_last, max_cur)");
+      return ORBHIP_ERR_CAPACITY;
+    }
+    A.big = reinterpret_cast<unsigned char*>(scratch) + ((orb_match_scratch_bytes(n_pairs, max_last) + 255) & ~(size_t)255);
+    A.big_stride = match_big_stride(max_cur);
+  }
   return launch_match<MODE_FRAMES>(A, n_pairs, stream);
 }
 
@@ -1200,7 +1283,8 @@ int orb_search_by_projection_frames_device(int device_id, int n_pairs, int max_l
   DevSel g(device_id);
   return frames_device_launch(n_pairs, max_last, max_cur, d_tcw, fx, fy, cx, cy, bounds, scale_factors, nlevels, d_n_last,
                               d_last_kps, d_last_mp_obs, d_last_xw, d_last_mp_desc, d_n_cur, d_cur_kps, d_cur_desc,
-                              d_cur_obs, th, check_orientation, d_scratch, d_cur_match, d_n_matches, (hipStream_t)stream);
+                              d_cur_obs, th, check_orientation, d_scratch, scratch_bytes, d_cur_match, d_n_matches,
+                              (hipStream_t)stream);
 }
 
 int orb_search_by_projection_frames_noalloc(int device_id, int n_pairs, int max_last, int max_cur, const float* d_tcw,
@@ -1221,6 +1305,11 @@ int orb_search_by_projection_frames_noalloc(int device_id, int n_pairs, int max_
               std::to_string(ORBHIP_NOALLOC_MAX_QUERIES) + " queries; use orb_search_by_projection_frames_device");
     return ORBHIP_ERR_CAPACITY;
   }
+  if (match_needs_big<MODE_FRAMES>(max_cur, max_last)) {
+    set_error("max_cur = " + std::to_string(max_cur) + " keypoints do not fit the on-chip grid (about 9000) and the large "
+              "form needs scratch per frame pair; use orb_search_by_projection_frames_device");
+    return ORBHIP_ERR_CAPACITY;
+  }
   DevSel g(device_id);
   void* sp = nullptr;
   int rc = noalloc_scratch_address(device_id, &sp);
@@ -1229,7 +1318,8 @@ int orb_search_by_projection_frames_noalloc(int device_id, int n_pairs, int max_
   // slice before it reads it
   return frames_device_launch(n_pairs, max_last, max_cur, d_tcw, fx, fy, cx, cy, bounds, scale_factors, nlevels, d_n_last,
                               d_last_kps, d_last_mp_obs, d_last_xw, d_last_mp_desc, d_n_cur, d_cur_kps, d_cur_desc,
-                              d_cur_obs, th, check_orientation, sp, d_cur_match, d_n_matches, (hipStream_t)stream);
+                              d_cur_obs, th, check_orientation, sp, sizeof(scratch), d_cur_match, d_n_matches,
+                              (hipStream_t)stream);
 }
 
 int orb_search_by_projection_mappoints(int device_id, OrbFrameBounds bounds, const float* scale_factors, int nlevels,
