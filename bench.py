@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=1,
                     help="1: the matcher of step k runs on a second stream beside the extraction of step k+1 "
                          "(two sets of keypoint buffers); 0: one stream")
+    ap.add_argument("--split", type=int, default=1,
+                    help="1: orb_extract_batch_device runs the batch as two staggered halves (its default); 0: on the "
+                         "caller's stream alone")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--knn-reps", type=int, default=3, help="timed repetitions of the kNN-2 leg (the median is reported)")
     ap.add_argument("--knn-popcount", type=int, default=1, help="1: also time the popcount kernel once on the same input")
@@ -214,18 +217,13 @@ def main():
             m_done[s].record(s_m)
 
     # ---------------- timed region ----------------
+    check(L.orb_extractor_set_batch_split(ex._h, args.split))
     for k in range(args.warmup):
         step(k)
     barrier()
-    L.orb_extractor_set_profiling(ex._h, 1)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    ev0.record()
     for k in range(args.steps):
-        step(k, ev_m0[k], ev_m1[k])
-    ev1.record()
+        step(k)
     barrier()
     t1 = time.perf_counter()
     red = torch.device("cpu") if share else dev  # where the timing reductions live (gloo: host)
@@ -233,6 +231,22 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    # ---------------- stage times: a pass of its own, after the timed region ----------------
+    # Every kernel alone on the GPU: the whole batch on one stream, the matcher after the extraction
+    # instead of beside the next one, HIP events between the stages on that stream (inside the library
+    # for the extractor's stages).  These are the kernel times `roofline` and `stage_gbs` are computed
+    # from; in the timed region above the stages of two half batches and the matcher overlap.
+    n_prof = max(1, min(args.steps, 10))
+    L.orb_extractor_set_profiling(ex._h, 1)
+    ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_prof)]
+    ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_prof)]
+    s_last = (args.steps - 1) % nsets if args.steps > 0 else 0
+    for k in range(n_prof):
+        chain.extract(s_last, s_ex.cuda_stream)
+        ev_m0[k].record(s_ex)
+        chain.match(s_last, s_ex.cuda_stream)
+        ev_m1[k].record(s_ex)
+    torch.cuda.synchronize()
     stage_ms = np.zeros(5, np.float32)
     check(L.orb_extractor_stage_times(ex._h, stage_ms.ctypes.data))
     L.orb_extractor_set_profiling(ex._h, 0)
@@ -499,7 +513,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "KITTI-shaped 1241x376 sequence, 2000 features, 8 levels, scale 1.2, FAST 20/7; "
                                    "extract + frame-to-frame SearchByProjection(th=7)",
-                       "frames_per_gpu_per_step": B, "streams": 2 if args.overlap else 1, "pairs_per_gpu_per_step": npairs,
+                       "frames_per_gpu_per_step": B, "streams": 2 if args.overlap else 1,
+                       "batch_split": bool(args.split and B >= 64), "pairs_per_gpu_per_step": npairs,
                        "keypoints_per_frame": round(nkp / B, 1), "matches_per_pair": round(nmatch / npairs, 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(gbs[dom], 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(gbs[dom] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom),
@@ -508,6 +523,9 @@ def main():
                          # priced as one: bytes and time of all of them, back to back on the stream
                          "launches_per_step": launches.get(dom, 1)},
             "stages_ms_per_step": stages,
+            "stages_measured": "separate pass after the timed region: whole batch on one stream, every kernel alone "
+                               "on the GPU (in the timed region two half batches and the matcher overlap, so the "
+                               "stages add up to more than ms_per_step)",
             "stage_gbs": {k: round(v, 1) for k, v in gbs.items()},
             "cpu_baseline": cpu,
             "knn2": knn,

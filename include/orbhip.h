@@ -138,8 +138,19 @@ int orb_extractor_set_opencv_compat(OrbExtractor* h, int major, int minor);
  * pixels).  No counterpart in the reference. */
 int orb_extractor_set_blur_fusion(OrbExtractor* h, int fused);
 
-/* Waits for the handle's own stream, which the host-buffer entry points and the
- * accessors below use. */
+/* orb_extract_batch_device with 64 frames or more runs the batch as two halves: the first on the
+ * caller's stream, the second on a stream of the handle's own, started one stage behind (after the
+ * first half's pyramid) and joined back into the caller's stream before the call returns, so that
+ * the bandwidth-bound pyramid of one half runs beside the issue-bound stages of the other.  Same
+ * results, same frame slots (every accessor works as before); the caller's stream sees the whole
+ * call as one piece of work.  enable == 0 keeps the batch on the caller's stream alone; with stage
+ * timing on, and on a stream under graph capture, it is kept there anyway.  Default: enabled.  No
+ * counterpart in the reference. */
+int orb_extractor_set_batch_split(OrbExtractor* h, int enable);
+
+/* Waits for everything the handle has queued: its own streams (which the host-buffer entry
+ * points and the accessors below use) and the last orb_extract_batch_device call on the caller's
+ * stream. */
 int orb_extractor_sync(OrbExtractor* h);
 
 /* Stage timing of the batch calls (no counterpart in the reference, which has no timers

@@ -37,7 +37,7 @@ EXPORTS = [
     "orb_last_error", "orb_device_count", "orb_extractor_create", "orb_extractor_destroy",
     "orb_extractor_get_scale_tables", "orb_extractor_get_level_quotas", "orb_extractor_max_keypoints",
     "orb_extract", "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync",
-    "orb_extractor_set_profiling", "orb_extractor_set_input_format", "orb_extractor_set_opencv_compat", "orb_extractor_set_blur_fusion", "orb_extractor_stage_times", "orb_match_scratch_bytes", "orb_match_scratch_bytes_for",
+    "orb_extractor_set_profiling", "orb_extractor_set_input_format", "orb_extractor_set_opencv_compat", "orb_extractor_set_blur_fusion", "orb_extractor_set_batch_split", "orb_extractor_stage_times", "orb_match_scratch_bytes", "orb_match_scratch_bytes_for",
     "orb_search_by_projection_frames_device", "orb_search_by_projection_frames_noalloc", "orb_match_windowed", "orb_match_windowed_keyframe", "orb_window_best_keyframe", "orb_stereo_match", "orb_search_by_bow", "orb_window_best", "orb_search_for_initialization",
     "orb_get_pyramid_level", "orb_get_blurred_level", "orb_get_fast_candidates", "orb_get_level_keypoints",
     "orb_hamming_distance_pairs", "orb_search_by_projection_frames", "orb_search_by_projection_mappoints",
@@ -79,6 +79,7 @@ def lib():
     L.orb_extractor_set_input_format.argtypes = [vp, i, i]
     L.orb_extractor_set_opencv_compat.argtypes = [vp, i, i]
     L.orb_extractor_set_blur_fusion.argtypes = [vp, i]
+    L.orb_extractor_set_batch_split.argtypes = [vp, i]
     L.orb_extractor_stage_times.argtypes = [vp, vp]
     L.orb_match_scratch_bytes.argtypes = [i, i]
     L.orb_match_scratch_bytes.restype = sz

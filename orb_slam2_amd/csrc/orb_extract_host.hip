@@ -32,6 +32,8 @@ void launch_orient_desc(const uint8_t*, const uint8_t*, const uint32_t*, const i
                         uint8_t*, int*, int, int, const int*, hipStream_t);
 void launch_pyr_resize_tile(uint8_t*, const Plan&, int, const uint32_t*, const YTab*, const int2*, int, const int2*, int,
                             int, int, int, int, hipStream_t);
+void launch_pyr_level01(const uint8_t*, size_t, size_t, uint8_t*, const Plan&, const uint32_t*, const YTab*, const int2*,
+                        int, const int2*, int, const int2*, int, int, int, int*, int, hipStream_t);
 int pyr_tile_cols();
 int pyr_tile_rows();
 int pyr_tile_rows_small();
@@ -173,6 +175,10 @@ struct OrbExtractor {
   // short tiles of pyr_tile_rows_small() rows that a few frames are cut into, so that a level of one
   // frame is spread over many workgroups instead of waiting for a handful of long ones
   struct TileInfo { bool ok = false; int xtp_off = 0, xr_off = 0, ngx = 0, src_pitch = 0; int yr_off[2] = {0, 0}, ngy[2] = {0, 0}, src_rows[2] = {0, 0}; };
+  // levels 0 and 1 in one launch (pyr_level01_kernel): usable for this plan, and where the table of
+  // the first level-0 row each tile row writes starts in d_ranges
+  bool fuse01 = false;
+  int own_off = 0;
   TileInfo tile[kMaxLevels];
   // launches of a few frames: level l and level l + 1 in one launch (pair[l].ok), see pyr_resize_dual_kernel
   struct PairInfo { bool ok = false; int spitch0 = 0, pitchB = 0, offB = 0, lds = 0; };
@@ -221,6 +227,12 @@ struct OrbExtractor {
   // reallocate, and the accessors, wait for that call's work instead of for the whole device.
   hipEvent_t done_ev = nullptr;
   bool done_pending = false;
+  // Device-buffer batches of kSplitMinFrames frames and more go through as two halves, the second on
+  // this stream and one stage behind the first: the pyramid of one half (bound by memory bandwidth)
+  // then runs beside FAST and the descriptor kernel of the other (bound by instruction issue).
+  hipStream_t half = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_stage = nullptr, ev_join = nullptr;
+  bool split_batches = true;
   bool async_alloc = false;  // the device has stream-ordered memory pools: buffers come from hipMallocAsync
   struct GraphKey {
     int n_frames = 0, rows = 0, cols = 0, max_kp = 0, channels = 0, rgb = 0, fused = 0;
@@ -241,6 +253,7 @@ constexpr int kSmallBatchFrames = 8;               // up to this many frames a l
 constexpr int kFewFrames = 4;                       // up to this many frames FAST takes shorter runs of cells
 constexpr int kPipeMinFrames = 64;                  // host-buffer batches from this size on go through in pieces
 constexpr int kPipePieces = 8;                      // ... at most this many
+constexpr int kSplitMinFrames = 64;                 // device-buffer batches from this size on run as two staggered halves
 constexpr int kGraphMaxFrames = 8;                 // batches up to this size replay a captured graph
 constexpr int kPoolThreads = 12;                   // host threads that pack a large batch (the caller is one)
 // ORBHIP_HOST_THREADS in the environment overrides that count (1 .. 64) for pools made afterwards
@@ -277,6 +290,7 @@ void drop_graph(OrbExtractor* h) {
 hipError_t wait_own(OrbExtractor* h) {
   hipError_t e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return e;
+  if (h->half && (e = hipStreamSynchronize(h->half)) != hipSuccess) return e;
   if (h->up && (e = hipStreamSynchronize(h->up)) != hipSuccess) return e;
   if (h->down && (e = hipStreamSynchronize(h->down)) != hipSuccess) return e;
   if (h->done_pending) {
@@ -474,6 +488,7 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
     // tables of the tiled resize kernel
     std::vector<uint32_t> xtp;
     std::vector<int2> ranges;
+    h->fuse01 = false;
     for (int l = 1; l < P.nlevels; l++) {
       const LevelGeom& L = P.lv[l];
       const LevelGeom& S = P.lv[l - 1];
@@ -527,6 +542,17 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
           if (r.y - r.x + 1 > pyr_tile_max_src_rows()) ti.ok = false;
         }
         ti.yr_off[v] = (int)ranges.size(); ranges.insert(ranges.end(), yr.begin(), yr.end());
+        if (l == 1 && v == 0) {
+          // level 0 written by the tiles of level 1: every image row must belong to exactly one tile
+          // row (the first that reads it), every 16-byte piece of a row to one tile column
+          bool fuse = ti.ok && yr[0].x == 0;
+          for (size_t g = 0; g + 1 < yr.size(); g++) fuse = fuse && yr[g + 1].x >= yr[g].x && yr[g + 1].x <= yr[g].y + 1;
+          for (size_t g = 0; g + 1 < xr.size(); g++) fuse = fuse && xr[g + 1].x >= xr[g].x && xr[g].y >= xr[g].x;
+          h->fuse01 = fuse;
+          h->own_off = (int)ranges.size();
+          for (const int2& r : yr) ranges.push_back(make_int2(r.x, 0));
+          ranges.push_back(make_int2(S.h, 0));
+        }
       }
       h->tile[l] = ti;
     }
@@ -578,7 +604,8 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
 // frame0: the batch's first frame takes slot frame0 of the handle's internal buffers (a host-buffer
 // batch that is processed in pieces keeps every frame's intermediate results)
 int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride, size_t frame_stride, int max_kp,
-            OrbKeyPoint* d_kps, uint8_t* d_desc, int* d_nout, hipStream_t st, int frame0 = 0) {
+            OrbKeyPoint* d_kps, uint8_t* d_desc, int* d_nout, hipStream_t st, int frame0 = 0,
+            hipEvent_t after_pyramid = nullptr, int hold_stage = 1) {
   const Plan& P = h->plan;
   uint8_t* const b_pyr = h->d_pyr + (size_t)frame0 * P.slab;
   uint8_t* const b_blur = h->d_blur + (size_t)frame0 * P.slab;
@@ -599,31 +626,48 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
     ev = h->ev.data() + (size_t)h->prof_calls * (ORBHIP_NUM_STAGES + 1);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[0], st));
+  static const int pyr_chunk = getenv("ORBHIP_PYR_CHUNK") ? atoi(getenv("ORBHIP_PYR_CHUNK")) : 0;
+  const int chunk = pyr_chunk > 0 && nframes > kSmallBatchFrames ? pyr_chunk : nframes;
+  for (int c0 = 0; c0 < nframes; c0 += chunk) {
+  const int cn = std::min(chunk, nframes - c0);
+  uint8_t* const c_pyr = b_pyr + (size_t)c0 * P.slab;
+  const uint8_t* const c_img = d_images + (size_t)c0 * frame_stride;
+  int* const c_cnt = b_cand_cnt + (size_t)c0 * P.nlevels;
   // (the level-0 kernel also clears the frames' candidate counters)
-  if (h->channels == 1) launch_pyr_level0(d_images, stride, frame_stride, b_pyr, P, b_cand_cnt, nframes, st);
-  else launch_pyr_level0_color(d_images, stride, frame_stride, h->channels, h->rgb_order, h->gray, b_pyr, P, b_cand_cnt, nframes, st);
-  for (int l = 1; l < P.nlevels; l++) {
+  static const bool fuse_off = getenv("ORBHIP_PYR_FUSE01") && getenv("ORBHIP_PYR_FUSE01")[0] == '0';
+  const bool fused01 = h->fuse01 && h->tile[1].ok && !fuse_off && h->channels == 1 && nframes > kSmallBatchFrames && P.nlevels > 1;
+  if (fused01) {
+    const OrbExtractor::TileInfo& ti = h->tile[1];
+    launch_pyr_level01(c_img, stride, frame_stride, c_pyr, P, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off,
+                       ti.ngx, h->d_ranges + ti.yr_off[0], ti.ngy[0], h->d_ranges + h->own_off, pyr_tile_rows(),
+                       ti.src_rows[0], ti.src_pitch, c_cnt, cn, st);
+  }
+  else if (h->channels == 1) launch_pyr_level0(c_img, stride, frame_stride, c_pyr, P, c_cnt, cn, st);
+  else launch_pyr_level0_color(c_img, stride, frame_stride, h->channels, h->rgb_order, h->gray, c_pyr, P, c_cnt, cn, st);
+  for (int l = fused01 ? 2 : 1; l < P.nlevels; l++) {
     const OrbExtractor::TileInfo& ti = h->tile[l];
     if (nframes <= kSmallBatchFrames && h->pair[l].ok) {
       const OrbExtractor::TileInfo& t2 = h->tile[l + 1];
       const OrbExtractor::PairInfo& pi = h->pair[l];
-      launch_pyr_resize_dual(b_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_xtp + t2.xtp_off, h->d_ytab,
+      launch_pyr_resize_dual(c_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_xtp + t2.xtp_off, h->d_ytab,
                              h->d_ranges + ti.xr_off, ti.ngx, h->d_ranges + ti.yr_off[1], ti.ngy[1],
                              h->d_ranges + t2.yr_off[1], t2.ngy[1], pyr_tile_rows_small(), ti.src_pitch, pi.spitch0,
-                             pi.pitchB, pi.offB, pi.lds, nframes, st);
+                             pi.pitchB, pi.offB, pi.lds, cn, st);
       l++;  // level l + 1 is done as well
       continue;
     }
     if (ti.ok) {
       const int v = nframes <= kSmallBatchFrames ? 1 : 0;
-      launch_pyr_resize_tile(b_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off, ti.ngx,
+      launch_pyr_resize_tile(c_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_ytab, h->d_ranges + ti.xr_off, ti.ngx,
                              h->d_ranges + ti.yr_off[v], ti.ngy[v], v ? pyr_tile_rows_small() : pyr_tile_rows(),
-                             ti.src_rows[v], ti.src_pitch, nframes, st);
+                             ti.src_rows[v], ti.src_pitch, cn, st);
     }
     else
-      launch_pyr_resize(b_pyr, P, l, h->d_xtab, h->d_ytab, nframes, st);
+      launch_pyr_resize(c_pyr, P, l, h->d_xtab, h->d_ytab, cn, st);
+  }
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[1], st));
+  if (after_pyramid && hold_stage == 1) ORB_HIP_CHECK(hipEventRecord(after_pyramid, st));
   {
     const int n_all = (int)h->fast_items.size(), n_batch = n_all - h->fast_items_few;
     if (nframes <= kFewFrames)
@@ -634,6 +678,7 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
                   b_cand_cnt, h->iniTh, h->minTh, nframes, st);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));
+  if (after_pyramid && hold_stage == 2) ORB_HIP_CHECK(hipEventRecord(after_pyramid, st));
   ORB_HIP_CHECK(launch_octree(b_cand, b_cand_cnt, b_pnode, b_sel, b_sel_cnt, P, h->ot_slots, nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[3], st));
   if (!h->fused_blur) launch_blur(b_pyr, b_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
@@ -761,6 +806,8 @@ void orb_extractor_destroy(OrbExtractor* h) {
   for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
   for (hipEvent_t e : h->pipe_ev) if (e) hipEventDestroy(e);
   if (h->done_ev) hipEventDestroy(h->done_ev);
+  for (hipEvent_t e : {h->ev_fork, h->ev_stage, h->ev_join}) if (e) hipEventDestroy(e);
+  if (h->half) hipStreamDestroy(h->half);
   if (h->up) hipStreamDestroy(h->up);
   if (h->down) hipStreamDestroy(h->down);
   hipStreamDestroy(h->stream);
@@ -810,13 +857,39 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
   DeviceGuard g(h->device);
   int rc = ensure_plan(h, rows, cols, n_frames);
   if (rc != ORBHIP_OK) return rc;
-  rc = enqueue(h, n_frames, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out,
-               (hipStream_t)stream);
-  if (rc != ORBHIP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  // Stage times are taken with the whole batch on one stream (kernels that share the GPU with another
+  // stage's would each read longer); a stream under capture is left to its owner.
+  const bool split = h->split_batches && n_frames >= kSplitMinFrames && !h->profiling && cap == hipStreamCaptureStatusNone;
+  if (split) {
+    if (!h->half) {
+      ORB_HIP_CHECK(hipStreamCreateWithFlags(&h->half, hipStreamNonBlocking));
+      ORB_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      ORB_HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+      ORB_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    const int n1 = n_frames / 2, n2 = n_frames - n1;
+    // the second half starts after whatever precedes this call on the caller's stream ...
+    ORB_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+    ORB_HIP_CHECK(hipStreamWaitEvent(h->half, h->ev_fork, 0));
+    static const int hold = getenv("ORBHIP_SPLIT_HOLD") ? atoi(getenv("ORBHIP_SPLIT_HOLD")) : 1;
+    rc = enqueue(h, n1, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out, st, 0, h->ev_stage, hold);
+    if (rc != ORBHIP_OK) return rc;
+    // ... and after the first half's pyramid: from then on the halves are a stage apart
+    if (hold) ORB_HIP_CHECK(hipStreamWaitEvent(h->half, h->ev_stage, 0));
+    rc = enqueue(h, n2, d_images + (size_t)n1 * frame_stride, stride, frame_stride, max_kp, d_keypoints + (size_t)n1 * max_kp,
+                 d_descriptors + (size_t)n1 * max_kp * 32, d_n_out + n1, h->half, n1);
+    if (rc != ORBHIP_OK) return rc;
+    ORB_HIP_CHECK(hipEventRecord(h->ev_join, h->half));
+    ORB_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+  } else {
+    rc = enqueue(h, n_frames, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out, st);
+    if (rc != ORBHIP_OK) return rc;
+  }
   // where this call's work ends on the caller's stream (a stream that is being captured into a graph
   // takes no such event: the capture's owner orders the replays)
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
   if (cap == hipStreamCaptureStatusNone) {
     ORB_HIP_CHECK(hipEventRecord(h->done_ev, (hipStream_t)stream));
     h->done_pending = true;
@@ -845,6 +918,12 @@ int orb_extractor_set_opencv_compat(OrbExtractor* h, int major, int minor) {
 int orb_extractor_set_blur_fusion(OrbExtractor* h, int fused) {
   if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
   h->fused_blur = fused != 0;
+  return ORBHIP_OK;
+}
+
+int orb_extractor_set_batch_split(OrbExtractor* h, int enable) {
+  if (!h) { set_error("null handle"); return ORBHIP_ERR_ARG; }
+  h->split_batches = enable != 0;
   return ORBHIP_OK;
 }
 

@@ -218,6 +218,8 @@ constexpr int PR_TC = 1024, PR_TR = 8, PR_TR_SMALL = 4, PR_THREADS = 256;  // ti
 constexpr int PR_SROWS = 32, PR_MAXPITCH = 1536;  // limits of the staged source region
 static_assert(sizeof(YTab) == 8, "a row's vertical taps are fetched as one 64-bit word");
 
+// STAGED: the caller has put the source rows into s_src already (pyr_level01_kernel)
+template <bool STAGED>
 __device__ __forceinline__ void pr_tile(uint8_t* __restrict__ pyr, unsigned long long slab, const LevelGeom& Ls,
                                         const LevelGeom& Ld, const uint32_t* __restrict__ xtp,
                                         const YTab* __restrict__ yt, const int2* __restrict__ xrange,
@@ -226,13 +228,15 @@ __device__ __forceinline__ void pr_tile(uint8_t* __restrict__ pyr, unsigned long
   const int tid = threadIdx.x;
   const int2 X = xrange[gx], Y = yrange[gy];
   const int a0 = (X.x + kXOff) & ~15;                  // first staged slab column
-  const int n16 = (X.y + kXOff - a0 + 16) >> 4;        // 16-byte pieces per row
-  const int nrows = Y.y - Y.x + 1;
-  const uint8_t* src = pyr + (size_t)f * slab + Ls.off + (size_t)(Y.x + kEdge) * Ls.pitch + a0;
-  for (int r = tid >> 6; r < nrows; r += PR_THREADS / 64)
-    for (int c = tid & 63; c < n16; c += 64)
-      *reinterpret_cast<uint4*>(&s_src[r * PR_SPITCH + 16 * c]) =
-          *reinterpret_cast<const uint4*>(src + (size_t)r * Ls.pitch + 16 * c);
+  if constexpr (!STAGED) {
+    const int n16 = (X.y + kXOff - a0 + 16) >> 4;        // 16-byte pieces per row
+    const int nrows = Y.y - Y.x + 1;
+    const uint8_t* src = pyr + (size_t)f * slab + Ls.off + (size_t)(Y.x + kEdge) * Ls.pitch + a0;
+    for (int r = tid >> 6; r < nrows; r += PR_THREADS / 64)
+      for (int c = tid & 63; c < n16; c += 64)
+        *reinterpret_cast<uint4*>(&s_src[r * PR_SPITCH + 16 * c]) =
+            *reinterpret_cast<const uint4*>(src + (size_t)r * Ls.pitch + 16 * c);
+  }
   // the rows' vertical taps: lane i of every wavefront fetches those of the tile's row i now (the
   // loop below reads them with v_readlane instead of waiting for a scalar load per row)
   // (tiles cover the level's own rows; the rows of the reflected frame above and below are copies
@@ -315,7 +319,112 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_tile_kernel(uint8_t* __
                                                                      int tile_rows) {
   // staged source rows: the launch sizes this to the level's widest / tallest tile
   extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
-  pr_tile(pyr, slab, Ls, Ld, xtp, yt, xrange, yrange, PR_SPITCH, tile_rows, blockIdx.z, blockIdx.y, blockIdx.x, s_src);
+  pr_tile<false>(pyr, slab, Ls, Ld, xtp, yt, xrange, yrange, PR_SPITCH, tile_rows, blockIdx.z, blockIdx.y, blockIdx.x, s_src);
+}
+
+// Levels 0 and 1 in one pass over the input image (one-channel input, batches): a workgroup is a
+// tile of level 1 as above, but takes the level-0 rows it needs from the IMAGE, and on the way
+// writes them into level 0's slab - each level-0 row by the first tile that needs it, each 16-byte
+// piece of it by the tile column whose staged range begins there - together with the reflected
+// frame: the columns left and right of a row with the row, the 19 rows above and below as copies
+// of rows 1 .. 19 and h - 20 .. h - 2.  Level 0 is then never read back for the resize, and the
+// pyramid is one launch shorter.  The host checks that consecutive tiles' source rows leave no gap
+// (every image row is then written by exactly one tile row).
+// own_rows[gy].x = first level-0 row tile row gy writes (own_rows[ngy].x = h).
+__global__ __launch_bounds__(PR_THREADS) void pyr_level01_kernel(
+    const uint8_t* __restrict__ img, size_t stride, size_t frame_stride, uint8_t* __restrict__ pyr,
+    unsigned long long slab, LevelGeom L0, LevelGeom L1, const uint32_t* __restrict__ xtp, const YTab* __restrict__ yt,
+    const int2* __restrict__ xrange, const int2* __restrict__ yrange, const int2* __restrict__ own_rows, int PR_SPITCH,
+    int tile_rows, int* __restrict__ cand_cnt, int nlevels) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
+  const int f = blockIdx.x, gy = blockIdx.y, gx = blockIdx.z, ngx = gridDim.z, tid = threadIdx.x;
+  // the frame's candidate counters start at zero (FAST, later in the stream, adds to them)
+  if (gy == 0 && gx == 0 && tid < nlevels) cand_cnt[f * nlevels + tid] = 0;
+  const int2 X = xrange[gx], Y = yrange[gy];
+  const int npieces = L0.pitch >> 4;
+  const int st0 = ((X.x + kXOff) & ~15) >> 4;             // staged pieces [st0, st1) of a slab row
+  const int st1 = st0 + ((X.y + kXOff - 16 * st0 + 16) >> 4);
+  const int ow0 = gx == 0 ? 0 : st0;                      // pieces this tile column writes to level 0
+  const int ow1 = gx + 1 < ngx ? ((xrange[gx + 1].x + kXOff) & ~15) >> 4 : npieces;
+  const int c_lo = min(ow0, st0), c_n = max(ow1, st1) - c_lo;
+  const int r_own1 = own_rows[gy + 1].x;                  // rows [Y.x, r_own1) are written, [Y.x, Y.y] staged
+  const int r_n = max(r_own1, Y.y + 1) - Y.x;
+  const uint8_t* const fimg = img + (size_t)f * frame_stride;
+  uint8_t* const dst0 = pyr + (size_t)f * slab + L0.off;
+  // where a finished 16-byte piece goes: the staged rows in LDS, level 0's slab, or both
+  auto put = [&](int r, int c, const uint4 out) {
+    if (c >= st0 && c < st1 && r <= Y.y) *reinterpret_cast<uint4*>(&s_src[(r - Y.x) * PR_SPITCH + 16 * (c - st0)]) = out;
+    if (c >= ow0 && c < ow1 && r < r_own1) {
+      uint8_t* d = dst0 + 16 * c;
+      *reinterpret_cast<uint4*>(d + (size_t)(r + kEdge) * L0.pitch) = out;
+      const int up = kEdge - r, down = kEdge + 2 * (L0.h - 1) - r;  // the row's mirror images in the frame
+      if (r >= 1 && up >= 0) *reinterpret_cast<uint4*>(d + (size_t)up * L0.pitch) = out;
+      if (r <= L0.h - 2 && down < L0.h + 2 * kEdge) *reinterpret_cast<uint4*>(d + (size_t)down * L0.pitch) = out;
+    }
+  };
+  // Interior pieces (16 c - kXOff >= 4 and 16 c - kXOff + 20 <= w: the five aligned dwords around
+  // the piece lie inside the image row) are numbered apart from the others, so that a wavefront
+  // runs one of the two paths, not both.
+  const int cf0 = max(c_lo, (kXOff + 4 + 15) / 16), cf1 = min(c_lo + c_n, (L0.w + kXOff - 20) / 16 + 1);
+  const int nf = max(cf1 - cf0, 0);
+  if (nf > 0) {
+    const uint32_t nf_m = (uint32_t)((1ull << 32) / (unsigned)nf + 1);  // t / nf by multiplication (t * nf < 2^32)
+    const int total = r_n * nf;
+    for (int t0 = tid; t0 < total; t0 += 2 * PR_THREADS) {
+      // two pieces per step, their loads issued together: four dwords in one load (any dword
+      // alignment) and the one after them, shifted into place
+      uint32_t x[2][5];
+      int rr[2], cc[2];
+      bool live[2];
+      uint32_t sh[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int t = t0 + u * PR_THREADS;
+        live[u] = t < total;
+        const int tt = live[u] ? t : 0;
+        const int ri = (int)__umulhi((uint32_t)tt, nf_m);
+        rr[u] = Y.x + ri;
+        cc[u] = cf0 + tt - ri * nf;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+        const uintptr_t a = reinterpret_cast<uintptr_t>(fimg + (size_t)rr[u] * stride + (16 * cc[u] - kXOff));
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+        sh[u] = (uint32_t)(a & 3);
+        const u32x4 V = *reinterpret_cast<const u32x4*>(q);
+        x[u][0] = V.x; x[u][1] = V.y; x[u][2] = V.z; x[u][3] = V.w;
+        x[u][4] = q[4];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (!live[u]) continue;
+        uint4 out;
+        out.x = __builtin_amdgcn_alignbyte(x[u][1], x[u][0], sh[u]);
+        out.y = __builtin_amdgcn_alignbyte(x[u][2], x[u][1], sh[u]);
+        out.z = __builtin_amdgcn_alignbyte(x[u][3], x[u][2], sh[u]);
+        out.w = __builtin_amdgcn_alignbyte(x[u][4], x[u][3], sh[u]);
+        put(rr[u], cc[u], out);
+      }
+    }
+  }
+  {
+    // the pieces on the frame or across a row's end: byte by byte, mirrored at the image's edges
+    const int nleft = nf > 0 ? cf0 - c_lo : c_n, nslow = c_n - nf;
+    const int total = r_n * nslow;
+    for (int t = tid; t < total; t += PR_THREADS) {
+      const int ri = t / nslow, j = t - ri * nslow;
+      const int r = Y.x + ri, c = j < nleft ? c_lo + j : cf1 + (j - nleft);
+      const uint8_t* S = fimg + (size_t)r * stride;
+      const int px0 = 16 * c - kXOff;
+      uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int px = px0 + k;
+        if (px >= -kEdge && px < L0.w + kEdge) o[k >> 2] |= (uint32_t)S[refl101(px, L0.w)] << (8 * (k & 3));
+      }
+      put(r, c, make_uint4(o[0], o[1], o[2], o[3]));
+    }
+  }
+  // (pr_tile's barrier comes before its first read of s_src)
+  pr_tile<true>(pyr, slab, L0, L1, xtp, yt, xrange, yrange, PR_SPITCH, tile_rows, gx, gy, f, s_src);
 }
 
 // Two levels in one launch, for launches of a few frames, where every level is a launch of a
@@ -332,7 +441,7 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_resize_dual_kernel(
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dual[];
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if ((int)blockIdx.y < ngy1) {  // uniform
-    pr_tile(pyr, slab, L0, L1, xtp1, yt + L1.ytab_off, xrange1, yrange1, spitch1, tile_rows, blockIdx.z, blockIdx.y, f, s_dual);
+    pr_tile<false>(pyr, slab, L0, L1, xtp1, yt + L1.ytab_off, xrange1, yrange1, spitch1, tile_rows, blockIdx.z, blockIdx.y, f, s_dual);
     return;
   }
   if (blockIdx.z != 0) return;
@@ -2058,6 +2167,14 @@ void launch_pyr_resize_dual(uint8_t* pyr, const Plan& P, int level, const uint32
   hipLaunchKernelGGL(pyr_resize_dual_kernel, dim3(nframes, ngy1 + ngy2, ngx1), dim3(PR_THREADS), (size_t)lds_bytes, st, pyr,
                      P.slab, P.lv[level - 1], P.lv[level], P.lv[level + 1], xtp1, xtp2, yt, xrange1, yrange1, yrange2,
                      spitch1, tile_rows, ngy1, spitch0, pitchB, offB);
+}
+void launch_pyr_level01(const uint8_t* img, size_t stride, size_t frame_stride, uint8_t* pyr, const Plan& P,
+                        const uint32_t* xtp, const YTab* yt, const int2* xrange, int ngx, const int2* yrange, int ngy,
+                        const int2* own_rows, int tile_rows, int src_rows, int src_pitch, int* cand_cnt, int nframes,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(pyr_level01_kernel, dim3(nframes, ngy, ngx), dim3(PR_THREADS), (size_t)src_rows * src_pitch, st, img,
+                     stride, frame_stride, pyr, P.slab, P.lv[0], P.lv[1], xtp, yt + P.lv[1].ytab_off, xrange, yrange,
+                     own_rows, src_pitch, tile_rows, cand_cnt, P.nlevels);
 }
 int pyr_tile_cols() { return PR_TC; }
 int pyr_tile_rows() { return PR_TR; }

@@ -707,3 +707,87 @@ def test_handle_changes_size_between_host_and_device_calls(oracle):
             k = d_k[0, :n].cpu().numpy().view(np.uint8).reshape(n, 24).copy().view(KP_DTYPE)[:, 0]
             d = d_d[0, :n].cpu().numpy()
         assert np.array_equal(k, wk) and np.array_equal(d, wd), it
+
+
+def test_device_batch_in_two_staggered_halves(oracle):
+    """orb_extract_batch_device runs batches of 64 frames and more as two halves on two streams, the
+    second one stage behind the first, joined on the caller's stream.  Keypoints and descriptors must
+    be those of the unsplit call, for an odd frame count, on a side stream, called twice in a row
+    without a wait in between; frames of both halves are read back stage by stage."""
+    import torch
+    from orb_slam2_amd import ORBextractor, _lib
+    from orb_slam2_amd._lib import KP_DTYPE
+    from orb_slam2_amd.synth import synth_sequence
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    rows, cols, n = 200, 333, 67
+    seq = synth_sequence(rows, cols, n, seed=8, step=3)
+    d_img = torch.from_numpy(seq).to(dev)
+    outs = []
+    side = torch.cuda.Stream(device=dev)
+    for split in (0, 1):
+        ex = ORBextractor(600, 1.2, 5, 20, 7)
+        _lib.check(L.orb_extractor_set_batch_split(ex._h, split))
+        cap = ex.max_keypoints(rows, cols)
+        k = torch.zeros((n, cap, 6), dtype=torch.float32, device=dev)
+        d = torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev)
+        c = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ex.extract_batch_device(d_img.data_ptr(), n, rows, cols, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap,
+                                    stream=side.cuda_stream)
+        with torch.cuda.stream(side):
+            total = c.sum()          # ordered after the call on the caller's stream only
+        side.synchronize()
+        outs.append((k.cpu().numpy(), d.cpu().numpy(), c.cpu().numpy(), int(total.item())))
+        if split:
+            ref = oracle.Extractor(600, 1.2, 5, 20, 7)
+            for f in (0, n // 2 - 1, n // 2, n - 1):
+                rk, rd = ref(seq[f])
+                m = int(outs[-1][2][f])
+                got = np.ascontiguousarray(outs[-1][0][f, :m]).view(KP_DTYPE).reshape(-1)
+                check_against(got, outs[-1][1][f, :m], rk, rd)
+                check_stages(ex, ref, 5, frame=f)
+    a, b = outs
+    assert a[3] == b[3] == int(a[2].sum()) and (a[2] > 50).all()
+    assert np.array_equal(a[2], b[2])
+    for f in range(n):
+        m = int(a[2][f])
+        assert np.array_equal(a[0][f, :m], b[0][f, :m]) and np.array_equal(a[1][f, :m], b[1][f, :m]), f
+
+
+def test_device_batch_from_strided_grey_images(oracle):
+    """Batches of more than 8 one-channel frames make pyramid levels 0 and 1 in one pass over the
+    input image: rows and frames with padding between them (odd byte counts, so every row has
+    another alignment), an odd image width and a width that is a multiple of 16; every stage of
+    the first and last frame against the oracle."""
+    import torch
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd._lib import KP_DTYPE
+    from orb_slam2_amd.synth import synth_sequence
+    dev = torch.device("cuda", 0)
+    for rows, cols, pad_r, pad_f in [(201, 333, 7, 13), (160, 320, 1, 0), (190, 1105, 3, 5)]:
+        n = 12
+        seq = synth_sequence(rows, cols, n, seed=cols, step=3)
+        stride, fstride = cols + pad_r, rows * (cols + pad_r) + pad_f
+        buf = np.full(n * fstride + 64, 255, np.uint8)
+        for f in range(n):
+            view = buf[f * fstride:f * fstride + rows * stride].reshape(rows, stride)
+            view[:, :cols] = seq[f]
+        d_buf = torch.from_numpy(buf).to(dev)
+        ex = ORBextractor(500, 1.2, 4, 20, 7)
+        cap = ex.max_keypoints(rows, cols)
+        k = torch.zeros((n, cap, 6), dtype=torch.float32, device=dev)
+        d = torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev)
+        c = torch.zeros(n, dtype=torch.int32, device=dev)
+        ex.set_input_format(1)
+        ex.extract_batch_device(d_buf.data_ptr(), n, rows, cols, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap,
+                                stream=torch.cuda.current_stream().cuda_stream, stride=stride, frame_stride=fstride)
+        torch.cuda.synchronize()
+        ref = oracle.Extractor(500, 1.2, 4, 20, 7)
+        for f in (0, n - 1):
+            rk, rd = ref(seq[f])
+            m = int(c[f])
+            got = np.ascontiguousarray(k[f, :m].cpu().numpy()).view(KP_DTYPE).reshape(-1)
+            check_against(got, d[f, :m].cpu().numpy(), rk, rd)
+            check_stages(ex, ref, 4, frame=f)
