@@ -106,3 +106,86 @@ def test_three_threads_match_and_extract_concurrently(oracle):
         t.join(150)
         assert not t.is_alive(), "a worker is stuck"
     assert not errors, errors
+
+
+def test_extractor_changes_size_and_reads_levels_while_matchers_run(oracle):
+    """The tracking thread's handle changes image size every other call (each change reallocates
+    its buffers) and reads a pyramid level and a blurred level back after every call, while two
+    other threads keep calling SearchByProjection and the medoid of ComputeDistinctiveDescriptors:
+    the allocations, releases and read-backs of one thread wait for that thread's own work only,
+    and everybody's results stay equal to the oracle's."""
+    from orb_slam2_amd import ORBextractor, _lib
+    from orb_slam2_amd._lib import FrameBounds, check, ptr
+    from orb_slam2_amd.synth import synth_image
+    L = _lib.lib()
+    shapes = [(240, 320), (200, 500), (376, 1241)]
+    imgs = [synth_image(r, c, seed=90 + i) for i, (r, c) in enumerate(shapes)]
+    refs = []
+    for im in imgs:
+        ref = oracle.Extractor(700, 1.2, 6, 20, 7)
+        rk, rd = ref(im)
+        refs.append((rk, rd, ref.pyramid_level(2), ref.blurred_level(1)))
+    ex = ORBextractor(700, 1.2, 6, 20, 7)
+
+    def run_extract(it):
+        i = (it // 2) % len(imgs)      # two calls per size, then the next size
+        k, d = ex(imgs[i])
+        rk, rd, lvl2, blur1 = refs[i]
+        assert len(k) == len(rk)
+        for f in ("x", "y", "octave", "response"):
+            assert np.array_equal(k[f], rk[f]), f
+        assert (d == rd).all(1).mean() >= 0.999
+        assert np.array_equal(ex.pyramid_level(2, padded=True), lvl2)
+        if blur1 is not None:
+            assert np.array_equal(ex.blurred_level(1), blur1)
+
+    rng = np.random.default_rng(12)
+    sc = projection_scene(rng, 1500, 1600, 376, 1241, conflict_clusters=20)
+    want_n, want_m = oracle.search_by_projection_frames(sc["Tcw"], sc["K"], sc["bounds"], sc["sf"], sc["last"], sc["cur"], 7.0, True)
+    La, Cu = sc["last"], sc["cur"]
+    nl, nc = len(La["octave"]), len(Cu["x"])
+    tcw = np.ascontiguousarray(sc["Tcw"].reshape(16), np.float32)
+    n_l, n_c = np.array([nl], np.int32), np.array([nc], np.int32)
+
+    def run_projection(it):
+        m, nm = np.zeros(nc, np.int32), np.zeros(1, np.int32)
+        K = sc["K"]
+        check(L.orb_search_by_projection_frames(
+            0, 1, nl, nc, ptr(tcw), float(K[0]), float(K[1]), float(K[2]), float(K[3]), FrameBounds(*sc["bounds"]),
+            ptr(sc["sf"]), 8, ptr(n_l), ptr(La["mp_obs"]), ptr(La["xw"]), ptr(La["mp_desc"]), ptr(La["octave"]), ptr(La["angle"]),
+            ptr(n_c), ptr(Cu["x"]), ptr(Cu["y"]), ptr(Cu["octave"]), ptr(Cu["angle"]), ptr(Cu["desc"]), ptr(Cu["obs"]),
+            7.0, 1, ptr(m), ptr(nm)))
+        assert int(nm[0]) == want_n and np.array_equal(m, want_m)
+
+    # map points with 2 .. 90 observing descriptors each (both medoid kernels), sizes that change per round
+    counts = rng.integers(2, 90, 300)
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    descs = rng.integers(0, 256, (int(start[-1]), 32), dtype=np.uint8)
+    want_med = np.array([oracle.distinctive_descriptor(descs[start[p]:start[p + 1]])[0] for p in range(len(counts))], np.int32)
+
+    def run_medoid(it):
+        npts = 100 + 100 * (it % 3)
+        bi, bm = np.zeros(npts, np.int32), np.zeros(npts, np.int32)
+        check(L.orb_distinctive_descriptors(0, npts, ptr(start), ptr(descs), ptr(bi), ptr(bm)))
+        assert np.array_equal(bi, want_med[:npts])
+
+    for f in (run_extract, run_projection, run_medoid):
+        f(0)
+    errors = []
+    go = threading.Barrier(3)
+
+    def worker(f):
+        try:
+            go.wait(timeout=60)
+            for it in range(ROUNDS):
+                f(it)
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errors.append((f.__name__, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(f,)) for f in (run_extract, run_projection, run_medoid)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(150)
+        assert not t.is_alive(), "a worker is stuck"
+    assert not errors, errors
