@@ -182,6 +182,7 @@ def main():
     nsets = 2 if args.overlap else 1
     chain = DeviceChain(ROWS, COLS, B, nfeatures=NFEAT, nlevels=NLEVELS, device=local, nsets=nsets, th=7.0,
                         check_orientation=True)
+    check(L.orb_extractor_set_batch_split(chain.ex._h, args.split))
     chain.load(seq)  # uploads the frames, extracts once, builds every frame's map points and the pair poses
     ex, max_kp, npairs = chain.ex, chain.max_kp, chain.npairs
     d_nout, d_nm = chain.nout[0], chain.d_nm
@@ -217,7 +218,6 @@ def main():
             m_done[s].record(s_m)
 
     # ---------------- timed region ----------------
-    check(L.orb_extractor_set_batch_split(ex._h, args.split))
     for k in range(args.warmup):
         step(k)
     barrier()
@@ -488,10 +488,14 @@ def main():
         # valid for the batch size they were taken at
         traffic, launches = {}, {}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json")))
             if tj["frames_per_launch"] == B:
                 traffic = {k.replace("_kernel", ""): v.get("hbm_bytes_per_step", v["hbm_bytes_per_launch"]) for k, v in tj["kernels"].items()}
                 launches = {k.replace("_kernel", ""): v.get("launches_per_step", 1) for k, v in tj["kernels"].items()}
+                # the pyramid stage is several kernels (levels 0 + 1 in one, then one launch per level)
+                pyr = [k for k in traffic if k.startswith("pyr_")]
+                traffic["pyramid"] = sum(traffic[k] for k in pyr)
+                launches["pyramid"] = sum(launches[k] for k in pyr)
         except (OSError, ValueError, KeyError):
             pass
         names = ["pyramid", "fast", "quadtree", "blur", "orient_desc"]

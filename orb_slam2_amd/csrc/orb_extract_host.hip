@@ -605,7 +605,7 @@ int ensure_plan(OrbExtractor* h, int rows, int cols, int nframes) {
 // batch that is processed in pieces keeps every frame's intermediate results)
 int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride, size_t frame_stride, int max_kp,
             OrbKeyPoint* d_kps, uint8_t* d_desc, int* d_nout, hipStream_t st, int frame0 = 0,
-            hipEvent_t after_pyramid = nullptr, int hold_stage = 1) {
+            hipEvent_t after_pyramid = nullptr) {
   const Plan& P = h->plan;
   uint8_t* const b_pyr = h->d_pyr + (size_t)frame0 * P.slab;
   uint8_t* const b_blur = h->d_blur + (size_t)frame0 * P.slab;
@@ -626,14 +626,12 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
     ev = h->ev.data() + (size_t)h->prof_calls * (ORBHIP_NUM_STAGES + 1);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[0], st));
-  static const int pyr_chunk = getenv("ORBHIP_PYR_CHUNK") ? atoi(getenv("ORBHIP_PYR_CHUNK")) : 0;
-  const int chunk = pyr_chunk > 0 && nframes > kSmallBatchFrames ? pyr_chunk : nframes;
-  for (int c0 = 0; c0 < nframes; c0 += chunk) {
-  const int cn = std::min(chunk, nframes - c0);
-  uint8_t* const c_pyr = b_pyr + (size_t)c0 * P.slab;
-  const uint8_t* const c_img = d_images + (size_t)c0 * frame_stride;
-  int* const c_cnt = b_cand_cnt + (size_t)c0 * P.nlevels;
+  const int cn = nframes;
+  uint8_t* const c_pyr = b_pyr;
+  const uint8_t* const c_img = d_images;
+  int* const c_cnt = b_cand_cnt;
   // (the level-0 kernel also clears the frames' candidate counters)
+  // (ORBHIP_PYR_FUSE01=0 in the environment keeps levels 0 and 1 in launches of their own: timing comparisons)
   static const bool fuse_off = getenv("ORBHIP_PYR_FUSE01") && getenv("ORBHIP_PYR_FUSE01")[0] == '0';
   const bool fused01 = h->fuse01 && h->tile[1].ok && !fuse_off && h->channels == 1 && nframes > kSmallBatchFrames && P.nlevels > 1;
   if (fused01) {
@@ -665,9 +663,8 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
     else
       launch_pyr_resize(c_pyr, P, l, h->d_xtab, h->d_ytab, cn, st);
   }
-  }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[1], st));
-  if (after_pyramid && hold_stage == 1) ORB_HIP_CHECK(hipEventRecord(after_pyramid, st));
+  if (after_pyramid) ORB_HIP_CHECK(hipEventRecord(after_pyramid, st));
   {
     const int n_all = (int)h->fast_items.size(), n_batch = n_all - h->fast_items_few;
     if (nframes <= kFewFrames)
@@ -678,7 +675,6 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
                   b_cand_cnt, h->iniTh, h->minTh, nframes, st);
   }
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[2], st));
-  if (after_pyramid && hold_stage == 2) ORB_HIP_CHECK(hipEventRecord(after_pyramid, st));
   ORB_HIP_CHECK(launch_octree(b_cand, b_cand_cnt, b_pnode, b_sel, b_sel_cnt, P, h->ot_slots, nframes, st));
   if (prof) ORB_HIP_CHECK(hipEventRecord(ev[3], st));
   if (!h->fused_blur) launch_blur(b_pyr, b_blur, P, h->d_blur_items, (int)h->blur_items.size(), h->taps, nframes, st);
@@ -874,11 +870,12 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
     // the second half starts after whatever precedes this call on the caller's stream ...
     ORB_HIP_CHECK(hipEventRecord(h->ev_fork, st));
     ORB_HIP_CHECK(hipStreamWaitEvent(h->half, h->ev_fork, 0));
-    static const int hold = getenv("ORBHIP_SPLIT_HOLD") ? atoi(getenv("ORBHIP_SPLIT_HOLD")) : 1;
-    rc = enqueue(h, n1, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out, st, 0, h->ev_stage, hold);
+    rc = enqueue(h, n1, d_images, stride, frame_stride, max_kp, d_keypoints, d_descriptors, d_n_out, st, 0, h->ev_stage);
     if (rc != ORBHIP_OK) return rc;
-    // ... and after the first half's pyramid: from then on the halves are a stage apart
-    if (hold) ORB_HIP_CHECK(hipStreamWaitEvent(h->half, h->ev_stage, 0));
+    // ... and after the first half's pyramid: from then on the halves are a stage apart (held back
+    // until the first half's FAST has ended, or not at all, the pair is slower: 1.28 / 1.22 against
+    // 1.21 ms per 256 frames)
+    ORB_HIP_CHECK(hipStreamWaitEvent(h->half, h->ev_stage, 0));
     rc = enqueue(h, n2, d_images + (size_t)n1 * frame_stride, stride, frame_stride, max_kp, d_keypoints + (size_t)n1 * max_kp,
                  d_descriptors + (size_t)n1 * max_kp * 32, d_n_out + n1, h->half, n1);
     if (rc != ORBHIP_OK) return rc;
