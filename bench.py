@@ -34,6 +34,7 @@ ROWS, COLS, NFEAT, NLEVELS = 376, 1241, 2000, 8
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 VALU_PEAK_LANEOPS = 256 * 64 * 2.4e9  # CUs x lanes x clock: peak 32-bit integer lane-ops/s
 MFMA_I8_PEAK_OPS = 2 * 1024 * 1024 * 2.4e9  # 2 x (SIMDs x int8 multiply-adds per cycle x clock): dense int8 peak
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4  # wave-level vector instructions per second: 1024 SIMDs, one per 4 cycles each
 
 
 def level_sizes(rows, cols, nlevels=8, f=1.2):
@@ -486,7 +487,7 @@ def main():
     if rank == 0:
         # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh + tools/pmc_to_traffic.py),
         # valid for the batch size they were taken at
-        traffic, launches = {}, {}
+        traffic, launches, valu = {}, {}, {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json")))
             if tj["frames_per_launch"] == B:
@@ -496,6 +497,12 @@ def main():
                 pyr = [k for k in traffic if k.startswith("pyr_")]
                 traffic["pyramid"] = sum(traffic[k] for k in pyr)
                 launches["pyramid"] = sum(launches[k] for k in pyr)
+                # wave-level vector instructions per step (SQ_INSTS_VALU of the same PMC passes)
+                per = {k.replace("_kernel", "").split("<")[0]: v.get("valu_insts_per_launch", 0) * v.get("launches_per_step", 1)
+                       for k, v in tj["kernels"].items()}
+                valu = {"pyramid": sum(v for k, v in per.items() if k.startswith("pyr_")), "fast": per.get("fast", 0),
+                        "quadtree": per.get("octree", 0), "orient_desc": per.get("orient_desc", 0),
+                        "search_by_projection": per.get("match", 0)}
         except (OSError, ValueError, KeyError):
             pass
         names = ["pyramid", "fast", "quadtree", "blur", "orient_desc"]
@@ -531,6 +538,11 @@ def main():
                                "on the GPU (in the timed region two half batches and the matcher overlap, so the "
                                "stages add up to more than ms_per_step)",
             "stage_gbs": {k: round(v, 1) for k, v in gbs.items()},
+            # what the stages are really bound by: the share of the chip's vector-instruction issue slots
+            # (1024 SIMDs, one wave instruction per 4 cycles at 2.4 GHz) each kernel fills while it runs alone;
+            # instruction counts from the committed PMC passes, times from this run
+            "stage_valu_issue_frac": {k: round(valu[k] / (stages[k] * 1e-3) / VALU_ISSUE_PEAK, 3)
+                                      for k in valu if valu[k] and stages.get(k)},
             "cpu_baseline": cpu,
             "knn2": knn,
         }

@@ -26,6 +26,10 @@ def per_kernel(d, counter):
 def main():
     fetch_dir, write_dir, out, frames = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     fc, wc = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    # optional fifth argument: the pass that holds SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU (wave-level vector instructions
+    # and the cycles the vector units were busy with them, summed over all SIMDs)
+    ic = per_kernel(sys.argv[5], "SQ_INSTS_VALU") if len(sys.argv) > 5 else {}
+    ac = per_kernel(sys.argv[5], "SQ_ACTIVE_INST_VALU") if len(sys.argv) > 5 else {}
     # steps of the profiled run = launches of a kernel that runs once per step (the quad-tree); a kernel
     # with several launches per step (the resize: one per level; FAST: two view heights) gets their sum too
     steps = max([n for k, (_, n) in fc.items() if "octree_kernel" in k] or [1])
@@ -40,6 +44,9 @@ def main():
         table[k.replace("orbhip::", "")] = {"fetch_size_kib_raw": round(f, 1), "write_size_kib": round(w, 1),
                                             "read_bytes": round(rd), "write_bytes": round(wr), "hbm_bytes_per_launch": round(rd + wr),
                                             "launches_per_step": round(per_step, 3), "hbm_bytes_per_step": round((rd + wr) * per_step)}
+        if k in ic:
+            table[k.replace("orbhip::", "")]["valu_insts_per_launch"] = round(ic[k][0])
+            table[k.replace("orbhip::", "")]["valu_active_cycles_per_launch"] = round(ac.get(k, (0.0, 0))[0])
     json.dump({"frames_per_launch": frames, "correction": "read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB",
                "kernels": table}, open(out, "w"), indent=1)
     print(json.dumps(table, indent=1))

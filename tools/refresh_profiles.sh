@@ -34,5 +34,5 @@ PY
   echo "# pass fetch (FETCH_SIZE in KiB at 64 B per request: double it for bytes read on gfx950, see r1_hbm_counter_calibration.txt)"; cat $src/pmc_fetch_sum.log
   echo "# pass write (WRITE_SIZE in KiB)"; cat $src/pmc_write_sum.log
   echo "# pass knn: python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --host-reps 0 --batch 8 --knn-reps 1 (1M x 1M; GRBM_GUI_ACTIVE is summed over the 8 XCDs)"; grep -i knn $src/pmc_knn_sum.log ) > profiles/${tag}_pmc_counters.txt
-python3 tools/pmc_to_traffic.py $src/pmc_fetch $src/pmc_write profiles/${tag}_traffic.json 256 > /dev/null
+python3 tools/pmc_to_traffic.py $src/pmc_fetch $src/pmc_write profiles/${tag}_traffic.json 256 $src/pmc_sq1 > /dev/null
 cut -c1-120 profiles/${tag}_kernel_stats.csv
