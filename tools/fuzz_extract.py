@@ -44,5 +44,22 @@ for case in range(n_cases):
         print("MISMATCH case %d %s: %d vs %d keypoints" % (case, tag, len(kps), len(rk)))
     elif case % 10 == 0:
         print("case %d %s ok (%d kp, desc identical %.4f) %.0fs" % (case, tag, len(kps), (desc == rd).all(1).mean() if len(kps) else 1.0, time.time() - t0), flush=True)
+    # the same image as the first and last frame of a batch (batches of more than 8 frames take other
+    # launches: levels 0 and 1 in one pass over the image, taller resize tiles, FAST by view height),
+    # the frames between them shifted copies; keypoints, descriptors and every padded level of both
+    nb = int(rng.integers(9, 14))
+    batch = np.stack([img] + [np.roll(img, int(rng.integers(1, 40)), axis=1) for _ in range(nb - 2)] + [img])
+    ref = O.Extractor(nf, sf, nlev, ini, mn)
+    rk, rd = ref(img)
+    bk, bd = ex.extract_batch(batch)
+    okb = True
+    for f in (0, nb - 1):
+        okb = okb and len(bk[f]) == len(rk) and all(np.array_equal(bk[f][n_], rk[n_]) for n_ in ("x", "y", "octave", "response", "size"))
+        okb = okb and (len(rk) == 0 or (bd[f] == rd).all(1).mean() >= 0.999)
+        for l in range(nlev):
+            okb = okb and np.array_equal(ex.pyramid_level(l, f, padded=True), ref.pyramid_level(l))
+    if not okb:
+        bad += 1
+        print("MISMATCH (batch of %d) case %d %s" % (nb, case, tag), flush=True)
 print("done: %d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)

@@ -39,6 +39,11 @@ for r in range(n_rounds):
     run("bow", T.test_search_by_bow_both_overloads, s, ri(100, 2500), ri(100, 2500), float(rng.uniform(0.6, 0.95)), bool(ri(0, 2)), ri(2, 300))
     run("init", T.test_search_for_initialization, s, ri(200, 3000), ri(10, 300), float(rng.uniform(0.7, 0.99)), bool(ri(0, 2)))
     run("knn", T.test_knn2_vs_oracle, ri(1, 3000), ri(1, 3000))
+    # frames beyond the on-chip grid (the second form of the kernel), every few rounds
+    if r % 3 == 0:
+        import test_operating_point_gpu as P
+        run("frames_large", lambda O_, *a: P._projection_case(O_, *a), s, ri(500, 6000), ri(9000, 25000), ri(0, 200), bool(ri(0, 2)))
+        run("init_large", P.test_search_for_initialization_at_the_shipped_size, s, ri(7400, 16000), ri(30, 200))
     print("round %d done, %d mismatches, %.0fs" % (r, bad, time.time() - t0), flush=True)
 print("done: %d rounds, %d mismatches" % (n_rounds, bad))
 sys.exit(1 if bad else 0)
