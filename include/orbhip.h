@@ -249,8 +249,8 @@ int orb_search_by_projection_frames(
  * d_last_* + p*max_last and d_cur_* + p*max_cur.  scale_factors is a HOST array.
  * d_scratch must hold orb_match_scratch_bytes(n_pairs, max_last) bytes.  Enqueued on
  * `stream`, not waited for; allocates nothing.
- * Size limits of the matchers: up to about 9000 train keypoints per frame (current-frame
- * keypoints here; about 7300 for orb_search_for_initialization) the keypoints' grid lives in
+ * Size limits of the matchers: up to about 7900 train keypoints per frame (current-frame
+ * keypoints here; about 6500 for orb_search_for_initialization) the keypoints' grid lives in
  * on-chip memory.  Larger frames, up to 65535 keypoints, take a second form of the kernel that
  * keeps part of it in global memory: the host-buffer entry points do that by themselves, the
  * device form needs d_scratch sized with orb_match_scratch_bytes_for(n_pairs, max_last, max_cur)

@@ -231,6 +231,7 @@ struct OrbExtractor {
   // this stream and one stage behind the first: the pyramid of one half (bound by memory bandwidth)
   // then runs beside FAST and the descriptor kernel of the other (bound by instruction issue).
   hipStream_t half = nullptr;
+  int half_prio = 0;
   hipEvent_t ev_fork = nullptr, ev_stage = nullptr, ev_join = nullptr;
   bool split_batches = true;
   bool async_alloc = false;  // the device has stream-ordered memory pools: buffers come from hipMallocAsync
@@ -860,8 +861,20 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
   // stage's would each read longer); a stream under capture is left to its owner.
   const bool split = h->split_batches && n_frames >= kSplitMinFrames && !h->profiling && cap == hipStreamCaptureStatusNone;
   if (split) {
+    // the second stream runs at the priority of the caller's: a caller that puts the extraction above
+    // other work on the GPU means both halves
+    int prio = 0;
+    if (hipStreamGetPriority(st, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    if (h->half && prio != h->half_prio) {
+      ORB_HIP_CHECK(hipStreamSynchronize(h->half));
+      ORB_HIP_CHECK(hipStreamDestroy(h->half));
+      h->half = nullptr;
+    }
     if (!h->half) {
-      ORB_HIP_CHECK(hipStreamCreateWithFlags(&h->half, hipStreamNonBlocking));
+      ORB_HIP_CHECK(hipStreamCreateWithPriority(&h->half, hipStreamNonBlocking, prio));
+      h->half_prio = prio;
+    }
+    if (!h->ev_fork) {
       ORB_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
       ORB_HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
       ORB_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));

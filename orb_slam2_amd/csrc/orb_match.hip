@@ -4,8 +4,10 @@
 // The reference matchers are greedy: a train keypoint taken by an earlier query is
 // skipped by later ones.  Each matcher kernel therefore has a parallel phase (every
 // query scans its candidates and keeps its few best, ordered exactly like the
-// reference's sequential scan would rank them) and a short ordered phase that
-// replays the reference's query order on those lists, 64 queries per step.
+// reference's sequential scan would rank them, and the queries that share a candidate
+// are joined into components) and an ordered phase that replays the reference's query
+// order on those lists: component by component, the components spread over the
+// workgroup's wavefronts, 64 queries per wavefront and step.
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -232,7 +234,8 @@ struct MatchArgs {
   int max_q, max_t, nlevels, check_ori;
   int keyframe_origin;  // window queries subtract the int-truncated origin (KeyFrame::GetFeaturesInArea)
   int lists_in_lds;  // the ranked candidate lists of all queries fit in LDS next to the grid
-  int desc_in_lds;   // the train descriptors are staged in LDS (chosen before the lists)
+  int desc_in_lds;   // the train descriptors are staged in LDS as well (small frames only: see launch_match)
+  int queue_cap;     // entries per thread in the window scans' queue (set by launch_match)
   int ts, qs;  // element stride (4-byte units) of t_x/t_y/t_oct/t_angle and of q_oct/q_angle:
                // 1 for separate arrays, 6 for fields of OrbKeyPoint records
   const int* n_q; const int* n_t;
@@ -256,7 +259,7 @@ struct MatchArgs {
   float f12[9];
   float ex, ey, th, nnratio;
   // scratch, per pair slices of max_q
-  uint2* lists; int* q_ntot; float4* q_geo; int* q_slot; int* q_bin;
+  uint32_t* lists; int* q_ntot; float4* q_geo; int* q_slot; int* q_bin;
   // frames with more train keypoints than fit in LDS (match_kernel<MODE, true>): per pair a block of
   // big_stride bytes that holds the keypoint coordinates, grid items and claim / owner words
   unsigned char* big; size_t big_stride;
@@ -264,36 +267,48 @@ struct MatchArgs {
   int* out_match; int* n_matches;
 };
 
-struct Cand { uint32_t key[MK]; uint32_t idx[MK]; int ntot; };
+// A ranked candidate is ONE word, distance << 16 | tie-break, smaller = better:
+//   grid modes: the tie-break is the candidate's slot in the grid-ordered arrays - the reference
+//     visits a window in that order and the first of equal distances wins - and the slot also
+//     names the keypoint (gmeta[slot] & 0xFFFF);
+//   SearchByBoW: the position in the vocabulary node's bucket (first minimum wins);
+//   SearchForTriangulation: 0xFFFF - position (the reference keeps the LAST of equal distances).
+// 0xFFFFFFFF = no candidate.  Four bytes per kept candidate instead of eight halve the lists, the
+// largest thing the replay needs on chip.
+struct Cand { uint32_t key[MK]; int ntot; };
+constexpr uint32_t kNoCand = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void cand_init(Cand& c) {
 #pragma unroll
-  for (int k = 0; k < MK; k++) { c.key[k] = 0xFFFFFFFFu; c.idx[k] = 0; }
+  for (int k = 0; k < MK; k++) c.key[k] = kNoCand;
   c.ntot = 0;
 }
-__device__ __forceinline__ void cand_insert(Cand& c, uint32_t key, uint32_t idx) {
+__device__ __forceinline__ void cand_insert(Cand& c, uint32_t key) {
   c.ntot++;
   if (key >= c.key[MK - 1]) return;
-  c.key[MK - 1] = key; c.idx[MK - 1] = idx;
+  c.key[MK - 1] = key;
 #pragma unroll
   for (int k = MK - 1; k > 0; k--) {
-    if (c.key[k] < c.key[k - 1]) {
-      const uint32_t tk = c.key[k]; c.key[k] = c.key[k - 1]; c.key[k - 1] = tk;
-      const uint32_t ti = c.idx[k]; c.idx[k] = c.idx[k - 1]; c.idx[k - 1] = ti;
-    }
+    if (c.key[k] < c.key[k - 1]) { const uint32_t tk = c.key[k]; c.key[k] = c.key[k - 1]; c.key[k - 1] = tk; }
   }
 }
 
 struct MatchShared {
   int* start;            // GRID_COLS*GRID_ROWS + 1
-  unsigned short* items; // max_t
-  float* kx; float* ky;  // max_t
+  unsigned short* queue; // queue_cap * M_THREADS: per thread, the slots of the items found in a window that still need their distance
+  // Grid modes: the train keypoints in GRID ORDER (cell by cell, ascending index inside a cell), as
+  // the scans walk them: coordinates in one 8-byte word, and index | octave << 16 | initial
+  // occupancy << 24 in another, so that an item outside the query's window - four out of five
+  // visited - costs one LDS read.  Bucketed modes: coordinates by keypoint index in kx / ky.
+  float2* gxy;           // max_t
+  uint32_t* gmeta;       // max_t
+  float* kx; float* ky;  // max_t (bucketed modes; the same memory as gxy)
   unsigned char* koct;   // max_t
   unsigned char* occ;    // max_t: train keypoint can no longer be taken
   int* claim;            // max_t: lowest pending lane that wants to take the keypoint
   const uint4* tdesc;    // train descriptors, two uint4 each (LDS copy if it fits, else global)
   int* owner;            // INIT: query that currently holds the train keypoint, -1 = none
-  uint2* lists;          // max_q * MK ranked candidates (LDS if it fits, else global scratch)
+  uint32_t* lists;       // max_q * MK ranked candidates (LDS if it fits, else global scratch)
   int* ntot;             // max_q: candidates seen (bit 30: the query's map point has observations), -1 = inactive
 };
 
@@ -309,6 +324,34 @@ template <bool BIG>
 __device__ __forceinline__ void word_store(int* p, int v) {
   if constexpr (BIG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
+}
+
+// Components of the conflict graph.  Two queries can influence each other only through a train
+// keypoint both can reach (one takes it, the other finds it taken), so the sequential loop of the
+// reference falls apart into independent loops, one per connected component of the graph "query -
+// candidate keypoint".  The components are found with a union-find over the train keypoints, kept
+// in S.claim: a word holds the keypoint's parent in its low 20 bits; the bits above are the lane
+// field the replay uses (kNoLane when idle).  Phase A unites every candidate a query ranks with the
+// query's first one; a pass after it points every word at its root.
+constexpr int kUfMask = 0xFFFFF, kNoLane = 0x7FF << 20;
+template <bool BIG>
+__device__ __forceinline__ int uf_find(int* P, int x) {
+  for (;;) {
+    const int p = word_load<BIG>(&P[x]) & kUfMask;
+    if (p == x) return x;
+    x = p;
+  }
+}
+template <bool BIG>
+__device__ __forceinline__ void uf_union(int* P, int a, int b) {
+  for (;;) {
+    a = uf_find<BIG>(P, a);
+    b = uf_find<BIG>(P, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }  // the larger root goes under the smaller one
+    if (atomicCAS(&P[a], kNoLane | a, kNoLane | b) == (kNoLane | a)) return;
+    // (somebody else moved a meanwhile: look again)
+  }
 }
 
 // Frame::GetFeaturesInArea (reference src/Frame.cc:371-449) fused with the best /
@@ -334,10 +377,39 @@ __device__ __forceinline__ int scan_dist_cap(const MatchArgs& A) {
   return 256;
 }
 
-template <int MODE>
+constexpr int kQueueMin = 2, kQueueMax = 8;  // entries per thread in the window scans' queues
+constexpr int kWorkBins = 256;
+static_assert(kWorkBins % 64 == 0 && kWorkBins < M_THREADS, "one wavefront scans the bins; the first threads clear them");
+
+// Cells of the grid that a query's window touches, Frame::GetFeaturesInArea (reference
+// src/Frame.cc:376-391); false if it lies outside the grid.
+__device__ __forceinline__ bool window_cells(const MatchArgs& A, const float4 geo, int& cx0, int& cx1, int& cy0, int& cy1) {
+  const float x = geo.x, y = geo.y, r = geo.z;
+  const float invW = (float)GRID_COLS / (A.b.max_x - A.b.min_x);
+  const float invH = (float)GRID_ROWS / (A.b.max_y - A.b.min_y);
+  cx0 = max(0, (int)floorf((x - A.q_min_x - r) * invW));
+  if (cx0 >= GRID_COLS) return false;
+  cx1 = min(GRID_COLS - 1, (int)ceilf((x - A.q_min_x + r) * invW));
+  if (cx1 < 0) return false;
+  cy0 = max(0, (int)floorf((y - A.q_min_y - r) * invH));
+  if (cy0 >= GRID_ROWS) return false;
+  cy1 = min(GRID_ROWS - 1, (int)ceilf((y - A.q_min_y + r) * invH));
+  if (cy1 < 0) return false;
+  return true;
+}
+
+// UNITE (phase A): the candidates that are ranked are also put into one component
+template <int MODE, bool UNITE = false, bool BIG = false>
 __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, int nt, const float4 geo,
                            const uint32_t* qd, int bucket0, int bucket1, float qx, float qy, Cand& c) {
   cand_init(c);
+  int first = -1;  // UNITE: the first candidate ranked
+  auto unite = [&](int j) {
+    if constexpr (UNITE) {
+      if (first < 0) first = j;
+      else uf_union<BIG>(S.claim, first, j);
+    }
+  };
   const uint4* tdesc = S.tdesc;
   const int dcap = scan_dist_cap<MODE>(A);
   (void)pair;
@@ -345,55 +417,94 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
     const float x = geo.x, y = geo.y, r = geo.z;
     const int lv = __float_as_int(geo.w);
     const int minLevel = (lv & 0xFFFF) - 1024, maxLevel = (lv >> 16) - 1024;
-    const float invW = (float)GRID_COLS / (A.b.max_x - A.b.min_x);
-    const float invH = (float)GRID_ROWS / (A.b.max_y - A.b.min_y);
-    const int nMinCellX = max(0, (int)floorf((x - A.q_min_x - r) * invW));
-    if (nMinCellX >= GRID_COLS) return;
-    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - A.q_min_x + r) * invW));
-    if (nMaxCellX < 0) return;
-    const int nMinCellY = max(0, (int)floorf((y - A.q_min_y - r) * invH));
-    if (nMinCellY >= GRID_ROWS) return;
-    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - A.q_min_y + r) * invH));
-    if (nMaxCellY < 0) return;
+    int nMinCellX, nMaxCellX, nMinCellY, nMaxCellY;
+    if (!window_cells(A, geo, nMinCellX, nMaxCellX, nMinCellY, nMaxCellY)) return;
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-    int pos = 0;
-    // the cells iy = nMinCellY..nMaxCellY of one grid column are adjacent in the CSR
-    // array, so a column of the window is one contiguous run of items
-    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-      const int pe = S.start[ix * GRID_ROWS + nMaxCellY + 1];
-      int p = S.start[ix * GRID_ROWS + nMinCellY];
-      int jn = p < pe ? (int)S.items[p] : 0;
-      while (p < pe) {
-        const int j = jn;
-        p++;
-        jn = p < pe ? (int)S.items[p] : 0;  // the next item is on its way while this one is tested
-        // everything the tests read, in one LDS round trip
-        const int oct = S.koct[j], occ = S.occ[j];
-        const float kxj = S.kx[j], kyj = S.ky[j];
+    // The cells iy = nMinCellY..nMaxCellY of one grid column are adjacent in the CSR array, so a
+    // column of the window is one contiguous run of items.  The scan alternates between two loops:
+    // the first walks the items and tests window, level and occupancy (two LDS reads per item, no
+    // dependent chain; four items in five drop out here) and queues the survivors; the second
+    // takes the queued items' distances and ranks them.  Side by side in one loop, every step of
+    // the wavefront would pay the second part's chain of latencies (descriptor, union-find,
+    // insertion) as soon as ONE of its 64 lanes has a survivor.
+    const int qcap = A.queue_cap;
+    unsigned short* const queue = S.queue + threadIdx.x;  // entry k at queue[k * M_THREADS]
+    int ix = nMinCellX;
+    int p = S.start[ix * GRID_ROWS + nMinCellY], pe = S.start[ix * GRID_ROWS + nMaxCellY + 1];
+    bool more = true;
+#ifdef ORB_MATCH_PROFILE
+    long long pf_fill = 0, pf_drain = 0; int pf_nf = 0, pf_nd = 0, pf_outer = 0;
+#endif
+    while (more) {
+      int n = 0;
+#ifdef ORB_MATCH_PROFILE
+      long long tq = wall_clock64(); pf_outer++;
+#endif
+      while (true) {
+#ifdef ORB_MATCH_PROFILE
+        pf_nf++;
+#endif
+        if (p >= pe) {
+          if (++ix > nMaxCellX) { more = false; break; }
+          p = S.start[ix * GRID_ROWS + nMinCellY]; pe = S.start[ix * GRID_ROWS + nMaxCellY + 1];
+          continue;
+        }
+        const float2 xy = S.gxy[p];
+        const uint32_t meta = S.gmeta[p];
+        const int slot = p++;
+        if (!(fabsf(xy.x - x) < r && fabsf(xy.y - y) < r)) continue;
+        const int oct = (int)((meta >> 16) & 0xFFu);
         if (bCheckLevels) {
           if (oct < minLevel) continue;
           if (maxLevel >= 0 && oct > maxLevel) continue;
         }
-        if (!(fabsf(kxj - x) < r && fabsf(kyj - y) < r)) continue;
-        const int mypos = pos++;
-        if (MODE != MODE_INIT && occ) continue;
+        // this scan runs before anything is decided: the occupancy is the initial one, held in the word
+        if (MODE != MODE_INIT && (meta >> 24)) continue;
         if constexpr (MODE == MODE_BEST) {
           if (A.chi2 > 0) {  // reference src/ORBmatcher.cc:1158-1164
-            const float ex = x - kxj, ey = y - kyj;
+            const float ex = x - xy.x, ey = y - xy.y;
             const float e2 = ex * ex + ey * ey;
             if ((double)(e2 * A.sigma2[min(oct, kMaxLevels - 1)]) > A.chi2) continue;
           }
         }
+        queue[n * M_THREADS] = (unsigned short)slot;
+        if (++n == qcap) break;
+      }
+#ifdef ORB_MATCH_PROFILE
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      pf_fill += wall_clock64() - tq; tq = wall_clock64();
+#endif
+      for (int k = 0; k < n; k++) {
+#ifdef ORB_MATCH_PROFILE
+        pf_nd++;
+#endif
+        const uint32_t slot = queue[k * M_THREADS];
+        const uint32_t meta = S.gmeta[slot];
+        const int j = (int)(meta & 0xFFFFu);
         const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
         if constexpr (MODE == MODE_INIT) {
           // occ = matched distance + 1 (0 = never matched): skip if vMatchedDistance[i2] <= dist
           // (reference src/ORBmatcher.cc:596)
+          const int occ = (int)(meta >> 24);
           if (occ && occ - 1 <= d) continue;
         }
         if (d > dcap) continue;
-        cand_insert(c, ((uint32_t)d << 20) | (uint32_t)mypos, (uint32_t)j);
+        unite(j);
+        cand_insert(c, ((uint32_t)d << 16) | slot);
       }
+#ifdef ORB_MATCH_PROFILE
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      pf_drain += wall_clock64() - tq;
+#endif
     }
+#ifdef ORB_MATCH_PROFILE_SCAN
+    if (UNITE && pair == 0) {
+      int mf = pf_nf, md = pf_nd, mo = pf_outer; long long mfill = pf_fill, mdr = pf_drain;
+      for (int o = 32; o >= 1; o >>= 1) { mf = max(mf, __shfl_xor(mf, o)); md = max(md, __shfl_xor(md, o)); mo = max(mo, __shfl_xor(mo, o));
+        mfill = max(mfill, __shfl_xor(mfill, o)); mdr = max(mdr, __shfl_xor(mdr, o)); }
+      if (threadIdx.x == 0) printf("scan wave 0: fill %lld (max lane iters %d) drain %lld (max lane items %d) outer %d qcap %d\n", mfill, mf, mdr, md, mo, qcap);
+    }
+#endif
     (void)nt;
   } else {
     // candidates: keyframe-2 features of the same vocabulary node, in order; the
@@ -406,7 +517,8 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
       if constexpr (MODE == MODE_BOW) {
         // SearchByBoW keeps best and second over the whole bucket; the first minimum wins
         if (d > dcap) continue;
-        cand_insert(c, ((uint32_t)d << 20) | (uint32_t)pos, (uint32_t)j);
+        unite(j);
+        cand_insert(c, ((uint32_t)d << 16) | (uint32_t)pos);
         continue;
       }
       if (d > TH_LOW) continue;
@@ -422,9 +534,96 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
       if (den == 0) continue;
       const float dsqr = num * num / den;
       if (!((double)dsqr < 3.84 * (double)A.sigma2[S.koct[j]])) continue;
-      cand_insert(c, ((uint32_t)d << 20) | (uint32_t)(0xFFFFF - pos), (uint32_t)j);
+      unite(j);
+      cand_insert(c, ((uint32_t)d << 16) | (uint32_t)(0xFFFF - pos));
     }
     (void)nt; (void)geo;
+  }
+}
+
+// scan_query for the replaying wavefront: all 64 lanes scan the candidates of ONE query (its
+// parameters are the same in every lane) against the live occupancy, 64 grid items at a time, and
+// every lane returns the query's two best (key, keypoint), key[k] = 0xFFFFFFFF if there is none.
+// A lane of its own takes several microseconds for this (forty items, each a chain of dependent
+// LDS and memory latencies) while the other 63 wait; together it is one or two rounds of loads.
+template <int MODE>
+__device__ void scan_query_wave(const MatchArgs& A, const MatchShared& S, const float4 geo, const uint32_t* qd,
+                                int bucket0, int bucket1, float qx, float qy, uint32_t (&key)[2], uint32_t (&idx)[2]) {
+  const int lane = threadIdx.x & 63;
+  uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, i0 = 0, i1 = 0;  // this lane's two smallest
+  auto take = [&](uint32_t k, uint32_t j) {
+    if (k < k0) { k1 = k0; i1 = i0; k0 = k; i0 = j; }
+    else if (k < k1) { k1 = k; i1 = j; }
+  };
+  const uint4* tdesc = S.tdesc;
+  const int dcap = scan_dist_cap<MODE>(A);
+  if constexpr (!mode_bucketed(MODE)) {
+    const float x = geo.x, y = geo.y, r = geo.z;
+    const int lv = __float_as_int(geo.w);
+    const int minLevel = (lv & 0xFFFF) - 1024, maxLevel = (lv >> 16) - 1024;
+    int nMinCellX, nMaxCellX, nMinCellY, nMaxCellY;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    if (window_cells(A, geo, nMinCellX, nMaxCellX, nMinCellY, nMaxCellY)) {
+      for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        const int pe = S.start[ix * GRID_ROWS + nMaxCellY + 1];
+        for (int pb = S.start[ix * GRID_ROWS + nMinCellY]; pb < pe; pb += 64) {
+          const int p = pb + lane;
+          const bool in = p < pe;
+          const float2 xyj = in ? S.gxy[p] : make_float2(0.f, 0.f);
+          const uint32_t meta = in ? S.gmeta[p] : 0u;
+          const int j = (int)(meta & 0xFFFFu), oct = (int)((meta >> 16) & 0xFFu);
+          const int occ = S.occ[j];  // the live occupancy
+          const float kxj = xyj.x, kyj = xyj.y;
+          bool pass = in && fabsf(kxj - x) < r && fabsf(kyj - y) < r;
+          if (bCheckLevels && (oct < minLevel || (maxLevel >= 0 && oct > maxLevel))) pass = false;
+          const int mypos = p;  // the slot in grid order breaks ties, as in scan_query
+          if (pass && (MODE == MODE_INIT || !occ)) {
+            const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+            const bool held = MODE == MODE_INIT && occ && occ - 1 <= d;  // reference src/ORBmatcher.cc:596
+            if (!held && d <= dcap) take(((uint32_t)d << 16) | (uint32_t)mypos, (uint32_t)j);
+          }
+        }
+      }
+    }
+  } else {
+    for (int pb = bucket0; pb < bucket1; pb += 64) {
+      const int p = pb + lane;
+      if (p >= bucket1) continue;
+      const int pos = p - bucket0;
+      const int j = A.items2[p];
+      if (S.occ[j]) continue;
+      const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+      if constexpr (MODE == MODE_BOW) {
+        if (d <= dcap) take(((uint32_t)d << 16) | (uint32_t)pos, (uint32_t)j);
+        continue;
+      }
+      if (d > TH_LOW) continue;
+      const float x2 = S.kx[j], y2 = S.ky[j];
+      const float distex = A.ex - x2, distey = A.ey - y2;
+      if (distex * distex + distey * distey < 100 * A.sf[S.koct[j]]) continue;
+      const float a = qx * A.f12[0] + qy * A.f12[3] + A.f12[6];
+      const float b = qx * A.f12[1] + qy * A.f12[4] + A.f12[7];
+      const float cc = qx * A.f12[2] + qy * A.f12[5] + A.f12[8];
+      const float num = a * x2 + b * y2 + cc;
+      const float den = a * a + b * b;
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (!((double)dsqr < 3.84 * (double)A.sigma2[S.koct[j]])) continue;
+      take(((uint32_t)d << 16) | (uint32_t)(0xFFFF - pos), (uint32_t)j);
+    }
+  }
+  // the two smallest keys of the wavefront (keys are distinct: each holds its item's rank)
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    unsigned long long best = ((unsigned long long)k0 << 32) | i0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long other = __shfl_xor(best, o);
+      best = other < best ? other : best;
+    }
+    key[r] = (uint32_t)(best >> 32);
+    idx[r] = (uint32_t)best;
+    if (k0 == key[r] && k0 != 0xFFFFFFFFu) { k0 = k1; i0 = i1; k1 = 0xFFFFFFFFu; }
   }
 }
 
@@ -441,27 +640,33 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_hist[HISTO_LENGTH];
   __shared__ int s_nm, s_keep[3];
+  __shared__ int s_bins[kWorkBins + 1];  // phase A: queries by the number of items they visit, most first
+  __shared__ int s_next;                 // phase A: next 64 queries of that order to hand out
+  __shared__ int s_chunk[M_THREADS / 64];
   const int pair = blockIdx.x, tid = threadIdx.x;
   const int nq = min(A.n_q[pair], A.max_q), nt = min(A.n_t[pair], A.max_t);
   MatchShared S;
   {
     unsigned char* p = smem;
     S.start = reinterpret_cast<int*>(p); p += sizeof(int) * (GRID_COLS * GRID_ROWS + 4);
+    S.queue = reinterpret_cast<unsigned short*>(p); p += sizeof(unsigned short) * M_THREADS * (size_t)A.queue_cap;
     if constexpr (BIG) {
       // LDS keeps the grid's offsets and the two byte arrays every candidate test reads; the rest
       // lives in the pair's block of global scratch (laid out by match_big_stride)
       S.koct = p; p += (A.max_t + 3) & ~3;
       S.occ = p; p += (A.max_t + 3) & ~3;
       unsigned char* g = A.big + (size_t)pair * A.big_stride;
+      S.gxy = reinterpret_cast<float2*>(g);
       S.kx = reinterpret_cast<float*>(g); g += sizeof(float) * A.max_t;
       S.ky = reinterpret_cast<float*>(g); g += sizeof(float) * A.max_t;
+      S.gmeta = reinterpret_cast<uint32_t*>(g); g += sizeof(uint32_t) * A.max_t;
       S.claim = reinterpret_cast<int*>(g); g += sizeof(int) * A.max_t;
-      S.owner = reinterpret_cast<int*>(g); g += sizeof(int) * A.max_t;
-      S.items = reinterpret_cast<unsigned short*>(g);
+      S.owner = reinterpret_cast<int*>(g);
     } else {
+      S.gxy = reinterpret_cast<float2*>(p);
       S.kx = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
       S.ky = reinterpret_cast<float*>(p); p += sizeof(float) * A.max_t;
-      S.items = reinterpret_cast<unsigned short*>(p); p += sizeof(unsigned short) * ((A.max_t + 1) & ~1);
+      S.gmeta = reinterpret_cast<uint32_t*>(p); p += sizeof(uint32_t) * A.max_t;
       S.koct = p; p += (A.max_t + 3) & ~3;
       S.occ = p; p += (A.max_t + 3) & ~3;
       S.claim = reinterpret_cast<int*>(p); p += sizeof(int) * A.max_t;
@@ -475,7 +680,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       S.tdesc = reinterpret_cast<const uint4*>(A.t_desc) + 2 * (size_t)pair * A.max_t;
     }
     if (A.lists_in_lds) {
-      S.lists = reinterpret_cast<uint2*>(p); p += sizeof(uint2) * MK * A.max_q;
+      S.lists = reinterpret_cast<uint32_t*>(p); p += sizeof(uint32_t) * MK * A.max_q;
       S.ntot = reinterpret_cast<int*>(p);
     } else {
       S.lists = A.lists + (size_t)pair * A.max_q * MK;
@@ -484,15 +689,22 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   }
   const size_t tbase = (size_t)pair * A.max_t, qbase = (size_t)pair * A.max_q;
   int* out_match = A.out_match + (mode_out_by_query(MODE) ? qbase : tbase);
+#ifdef ORB_MATCH_PROFILE
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PT(k) pt[k] = wall_clock64()
+#else
+#define PT(k)
+#endif
+  PT(0);
 
   // ---- phase 0: train keypoints to LDS; 64x48 grid as CSR in insertion order
   // (Frame::AssignFeaturesToGrid / PosInGrid, reference src/Frame.cc:190-213, 461-477)
   for (int j = tid; j < nt; j += M_THREADS) {
-    S.kx[j] = A.t_x[(tbase + j) * A.ts]; S.ky[j] = A.t_y[(tbase + j) * A.ts];
+    if (mode_bucketed(MODE)) { S.kx[j] = A.t_x[(tbase + j) * A.ts]; S.ky[j] = A.t_y[(tbase + j) * A.ts]; }
     S.koct[j] = (unsigned char)min(max(A.t_oct[(tbase + j) * A.ts], 0), 255);
     S.occ[j] = (unsigned char)(A.t_obs[tbase + j] > 0);
     if (MODE == MODE_INIT) S.owner[j] = -1;
-    S.claim[j] = 0x7FFFFFFF;
+    S.claim[j] = kNoLane | j;  // every keypoint a component of its own, nobody replaying it
     if (!mode_out_by_query(MODE)) out_match[j] = -1;
   }
   if (A.desc_in_lds) {
@@ -503,7 +715,8 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   if (mode_bucketed(MODE) || MODE == MODE_INIT)
     for (int i = tid; i < A.max_q; i += M_THREADS) out_match[i] = -1;
   if (tid < HISTO_LENGTH) s_hist[tid] = 0;
-  if (tid == 0) s_nm = 0;
+  if (tid <= kWorkBins) s_bins[tid] = 0;
+  if (tid == 0) { s_nm = 0; s_next = 0; }
   if constexpr (!mode_bucketed(MODE)) {
     constexpr int NC = GRID_COLS * GRID_ROWS;
     // counts go to start[cell + 2]; after the inclusive scan start[cell + 1] is the
@@ -514,7 +727,8 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     const float invW = (float)GRID_COLS / (A.b.max_x - A.b.min_x);
     const float invH = (float)GRID_ROWS / (A.b.max_y - A.b.min_y);
     for (int j = tid; j < nt; j += M_THREADS) {
-      const int px = (int)roundf((S.kx[j] - A.b.min_x) * invW), py = (int)roundf((S.ky[j] - A.b.min_y) * invH);
+      const float kxj = A.t_x[(tbase + j) * A.ts], kyj = A.t_y[(tbase + j) * A.ts];
+      const int px = (int)roundf((kxj - A.b.min_x) * invW), py = (int)roundf((kyj - A.b.min_y) * invH);
       if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) atomicAdd(&S.start[px * GRID_ROWS + py + 2], 1);
     }
     __syncthreads();
@@ -529,31 +743,38 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     }
     __syncthreads();
     for (int j = tid; j < nt; j += M_THREADS) {
-      const int px = (int)roundf((S.kx[j] - A.b.min_x) * invW), py = (int)roundf((S.ky[j] - A.b.min_y) * invH);
-      if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS)
-        S.items[atomicAdd(&S.start[px * GRID_ROWS + py + 1], 1)] = (unsigned short)j;
+      const float kxj = A.t_x[(tbase + j) * A.ts], kyj = A.t_y[(tbase + j) * A.ts];  // (served by the caches: read a moment ago)
+      const int px = (int)roundf((kxj - A.b.min_x) * invW), py = (int)roundf((kyj - A.b.min_y) * invH);
+      if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) {
+        const int slot = atomicAdd(&S.start[px * GRID_ROWS + py + 1], 1);
+        S.gxy[slot] = make_float2(kxj, kyj);
+        S.gmeta[slot] = (uint32_t)j | ((uint32_t)S.koct[j] << 16) | ((uint32_t)S.occ[j] << 24);
+      }
     }
     __syncthreads();
-    // insertion order inside a cell is ascending keypoint index
+    // insertion order inside a cell is ascending keypoint index (the low 16 bits of the second word)
     for (int c = tid; c < NC; c += M_THREADS) {
       const int b = S.start[c], e = S.start[c + 1];
       for (int i = b + 1; i < e; i++) {
-        const unsigned short v = S.items[i];
+        const uint32_t v = S.gmeta[i];
+        const float2 w = S.gxy[i];
         int k = i - 1;
-        while (k >= b && S.items[k] > v) { S.items[k + 1] = S.items[k]; k--; }
-        S.items[k + 1] = v;
+        while (k >= b && (S.gmeta[k] & 0xFFFFu) > (v & 0xFFFFu)) { S.gmeta[k + 1] = S.gmeta[k]; S.gxy[k + 1] = S.gxy[k]; k--; }
+        S.gmeta[k + 1] = v; S.gxy[k + 1] = w;
       }
     }
   }
   __syncthreads();
+  PT(1);
 
-  // ---- phase A: every query ranks its candidates against the initial occupancy
-  for (int i = tid; i < nq; i += M_THREADS) {
-    float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- phase A: every query ranks its candidates against the initial occupancy.
+  // A wavefront scans 64 queries in lockstep and takes as long as the one with the most items to
+  // visit; windows grow with the pyramid level (a level-7 window holds twelve times the items of a
+  // level-0 one) and vocabulary buckets differ as much.  So the queries are first counted into
+  // bins by the number of items they will visit and handed to the lanes in descending order of it:
+  // the 64 queries of a wavefront then have about the same length.
+  auto setup = [&](int i, float4& geo, int& b0, int& b1, float& qx, float& qy, const uint8_t*& qdesc_ptr) -> bool {
     bool valid = true;
-    int b0 = 0, b1 = 0;
-    float qx = 0.f, qy = 0.f;
-    const uint8_t* qdesc_ptr;
     if constexpr (MODE == MODE_FRAMES) {
       // projection, reference src/ORBmatcher.cc:1669-1712
       valid = A.q_obs[qbase + i] >= 0;
@@ -595,104 +816,253 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       qx = A.q_x[qbase + idx1]; qy = A.q_y[qbase + idx1];
       qdesc_ptr = A.q_desc + 32 * (qbase + idx1);
     }
-    Cand c;
-    cand_init(c);
-    if (valid) {
-      const uint4 d0 = reinterpret_cast<const uint4*>(qdesc_ptr)[0], d1 = reinterpret_cast<const uint4*>(qdesc_ptr)[1];
-      const uint32_t qd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-      scan_query<MODE>(A, S, pair, nt, geo, qd, b0, b1, qx, qy, c);
+    return valid;
+  };
+  int* const order = A.q_bin + qbase;  // (the rotation bins of phase C are not in use yet)
+  for (int i = tid; i < nq; i += M_THREADS) {
+    float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
+    int b0 = 0, b1 = 0;
+    float qx = 0.f, qy = 0.f;
+    const uint8_t* qdesc_ptr;
+    const bool valid = setup(i, geo, b0, b1, qx, qy, qdesc_ptr);
+    int work = b1 - b0;
+    if constexpr (!mode_bucketed(MODE)) {
+      int cx0, cx1, cy0, cy1;
+      work = 0;
+      if (window_cells(A, geo, cx0, cx1, cy0, cy1))
+        for (int ix = cx0; ix <= cx1; ix++) work += S.start[ix * GRID_ROWS + cy1 + 1] - S.start[ix * GRID_ROWS + cy0];
     }
-    if constexpr (MODE == MODE_BEST) {
-      // independent queries: the first minimum is the result
-      const bool any = c.key[0] != 0xFFFFFFFFu;
-      A.out_match[qbase + i] = any ? (int)c.idx[0] : -1;
-      A.out_dist[qbase + i] = any ? (int)(c.key[0] >> 20) : 0x7FFFFFFF;
+    if (valid && work > 0) {
+      if (!mode_bucketed(MODE)) A.q_geo[qbase + i] = geo;  // (the scan below reads it again, and so do the replay's rescans)
+      S.ntot[i] = work;
+      atomicAdd(&s_bins[kWorkBins - 1 - min(work, kWorkBins - 1)], 1);
       continue;
     }
-    A.q_geo[qbase + i] = geo;
-    int obs_bit = 0;
-    if (MODE == MODE_FRAMES || MODE == MODE_MAPPOINTS) obs_bit = A.q_obs[qbase + i] > 0 ? 0x40000000 : 0;
-    S.ntot[i] = valid ? (c.ntot | obs_bit) : -1;
+    // nothing to scan: the query's results are final here
+    if constexpr (MODE == MODE_BEST) {
+      A.out_match[qbase + i] = -1;
+      A.out_dist[qbase + i] = 0x7FFFFFFF;
+      S.ntot[i] = -1;
+    } else {
+      A.q_geo[qbase + i] = geo;
+      int obs_bit = 0;
+      if (MODE == MODE_FRAMES || MODE == MODE_MAPPOINTS) obs_bit = A.q_obs[qbase + i] > 0 ? 0x40000000 : 0;
+      S.ntot[i] = valid ? obs_bit : -1;
 #pragma unroll
-    for (int k = 0; k < MK; k++) S.lists[i * MK + k] = make_uint2(c.key[k], c.idx[k]);
-    A.q_slot[qbase + i] = -1;
+      for (int k = 0; k < MK; k++) S.lists[i * MK + k] = kNoCand;
+      A.q_slot[qbase + i] = -1;
+    }
   }
   __syncthreads();
-  if constexpr (MODE == MODE_BEST) return;
-
-  // ---- phase B: replay the reference's query order, 64 queries per step
-  if (tid < 64) {
-    const int lane = tid;
-    // the lists of the next 64 queries are fetched while the current ones are replayed
-    // (they may live in global memory)
-    uint2 nl[MK];
-    int n_ntot = -1;
-    auto fetch = [&](int base) {
-      const int i = base + lane;
-      n_ntot = i < nq ? S.ntot[i] : -1;
+  if (tid < 64) {  // exclusive scan of the bins, kWorkBins / 64 per lane
+    constexpr int PER = kWorkBins / 64;
+    int sum = 0;
+    for (int k = 0; k < PER; k++) sum += s_bins[tid * PER + k];
+    int incl = sum;
 #pragma unroll
-      for (int k = 0; k < MK; k++) nl[k] = i < nq ? S.lists[i * MK + k] : make_uint2(0xFFFFFFFFu, 0u);
-    };
-    fetch(0);
-    for (int base = 0; base < nq; base += 64) {
-      const int i = base + lane;
-      const int nt_i = n_ntot;
-      const bool active = nt_i > 0 && (nt_i & 0x3FFFFFFF) > 0;
-      const bool q_occupies = (nt_i & 0x40000000) != 0;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (tid >= o) incl += v; }
+    int run = incl - sum;
+    for (int k = 0; k < PER; k++) { const int v = s_bins[tid * PER + k]; s_bins[tid * PER + k] = run; run += v; }
+    if (tid == 63) s_bins[kWorkBins] = run;  // queries to scan
+  }
+  __syncthreads();
+  const int n_scan = s_bins[kWorkBins];
+  for (int i = tid; i < nq; i += M_THREADS) {
+    // (this thread wrote the word itself: the count where the query is to be scanned, else a final
+    // value, which is negative or has none of the count's bits - counts are below 2^30 and not 0)
+    const int work = S.ntot[i];
+    const bool scan = work > 0 && !(work & 0x40000000);
+    if (scan) __hip_atomic_store(&order[atomicAdd(&s_bins[kWorkBins - 1 - min(work, kWorkBins - 1)], 1)], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+#ifdef ORB_MATCH_PROFILE
+  PT(6);
+#endif
+  for (;;) {
+    // A wavefront takes the next 64 queries of the order when it is done with its last ones: the
+    // longest first, so the wavefronts end about together.  (Every lane reads the chunk's number
+    // from the wavefront's word, and nothing below leaves the loop's body early: all 64 lanes
+    // come back to this point together.)
+    if ((tid & 63) == 0) s_chunk[tid >> 6] = atomicAdd(&s_next, 1);
+    __builtin_amdgcn_wave_barrier();
+    const int chunk = s_chunk[tid >> 6];
+    __builtin_amdgcn_wave_barrier();
+    if (chunk * 64 >= n_scan) break;
+    const int k = chunk * 64 + (tid & 63);
+    if (k < n_scan) {
+      const int i = __hip_atomic_load(&order[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
+      int b0 = 0, b1 = 0;
+      float qx = 0.f, qy = 0.f;
+      const uint8_t* qdesc_ptr;
+      if constexpr (mode_bucketed(MODE)) {
+        setup(i, geo, b0, b1, qx, qy, qdesc_ptr);
+      } else {
+        geo = A.q_geo[qbase + i];  // (written before the barrier, and never read before in this launch)
+        qdesc_ptr = A.q_desc + 32 * (qbase + i);
+      }
       Cand c;
       cand_init(c);
-      int my_idx1 = 0;
-      if (active) {
-#pragma unroll
-        for (int k = 0; k < MK; k++) { c.key[k] = nl[k].x; c.idx[k] = nl[k].y; }
-        c.ntot = nt_i & 0x3FFFFFFF;
-        if (mode_bucketed(MODE)) my_idx1 = A.q_idx1[qbase + i];
+      {
+        const uint4 d0 = reinterpret_cast<const uint4*>(qdesc_ptr)[0], d1 = reinterpret_cast<const uint4*>(qdesc_ptr)[1];
+        const uint32_t qd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        scan_query<MODE, MODE != MODE_BEST, BIG>(A, S, pair, nt, geo, qd, b0, b1, qx, qy, c);
       }
-      if (base + 64 < nq) fetch(base + 64);
+      if constexpr (MODE == MODE_BEST) {
+        // independent queries: the first minimum is the result
+        const bool any = c.key[0] != kNoCand;
+        A.out_match[qbase + i] = any ? (int)(S.gmeta[c.key[0] & 0xFFFFu] & 0xFFFFu) : -1;
+        A.out_dist[qbase + i] = any ? (int)(c.key[0] >> 16) : 0x7FFFFFFF;
+      } else {
+        if (mode_bucketed(MODE)) A.q_geo[qbase + i] = geo;
+        int obs_bit = 0;
+        if (MODE == MODE_FRAMES || MODE == MODE_MAPPOINTS) obs_bit = A.q_obs[qbase + i] > 0 ? 0x40000000 : 0;
+        S.ntot[i] = c.ntot | obs_bit;
+#pragma unroll
+        for (int k2 = 0; k2 < MK; k2++) S.lists[i * MK + k2] = c.key[k2];
+        A.q_slot[qbase + i] = -1;
+      }
+    }
+  }
+  __syncthreads();
+  PT(2);
+  if constexpr (MODE == MODE_BEST) return;
+  // every keypoint's word straight at its component's root (one read per query in the replay)
+  for (int j = tid; j < nt; j += M_THREADS) word_store<BIG>(&S.claim[j], kNoLane | uf_find<BIG>(S.claim, j));
+  __syncthreads();
+  // the keypoint a candidate's word names
+  auto cand_keypoint = [&](uint32_t word, int b0) -> uint32_t {
+    const uint32_t tie = word & 0xFFFFu;
+    if constexpr (MODE == MODE_TRIANG) return (uint32_t)A.items2[b0 + (int)(0xFFFFu - tie)];
+    else if constexpr (MODE == MODE_BOW) return (uint32_t)A.items2[b0 + (int)tie];
+    else return S.gmeta[tie] & 0xFFFFu;
+  };
+  // Components are independent loops, so the wavefronts share them out: a query goes to the
+  // wavefront its component's root hashes to (bits 24-27 of its count word; bits 0-15 are the
+  // count, bit 30 the observation flag, a negative word an inactive query).
+  constexpr int kWaves = M_THREADS / 64;
+  static_assert(kWaves == 16, "four bits of the count word name the wavefront");
+  for (int i = tid; i < nq; i += M_THREADS) {
+    const int w = S.ntot[i];
+    const uint32_t first = S.lists[i * MK];
+    if (w > 0 && (w & 0xFFFF) > 0 && first != kNoCand) {
+      int b0 = 0;
+      if constexpr (mode_bucketed(MODE)) b0 = A.q_b0[qbase + i];
+      const int root = word_load<BIG>(&S.claim[cand_keypoint(first, b0)]) & kUfMask;
+      S.ntot[i] = w | (((root ^ (root >> 4) ^ (root >> 8)) & (kWaves - 1)) << 24);
+    } else if (w > 0) {
+      S.ntot[i] = w & 0x40000000;  // nothing ranked: nothing to replay
+    }
+  }
+  __syncthreads();
+  PT(3);
+
+  // ---- phase B: replay the reference's query order.  Every wavefront walks the queries in
+  // ascending order, gathers its own 64 at a time and decides them; within such a step the queries of
+  // one component are decided in ascending order, one per round (the lowest pending lane of the
+  // component, found with an atomic minimum on the root's word), and different components, which
+  // do not touch each other's keypoints, go side by side - in the step and across the wavefronts.
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    // gathered queries, up to 63 left over + 64 new: in the scans' queues, which are idle now
+    static_assert(kQueueMin * M_THREADS >= 128 * kWaves, "the queues' minimum holds every wavefront's gathered queries");
+    unsigned short* const stage = S.queue + 128 * wave;
+    int have = 0, base = 0;
+    for (;;) {
+      while (have < 64 && base < nq) {  // (wavefront-uniform)
+        const int i = base + lane;
+        const int w = i < nq ? S.ntot[i] : -1;
+        const bool own = w > 0 && (w & 0xFFFF) > 0 && ((w >> 24) & (kWaves - 1)) == wave;
+        const unsigned long long m = __ballot(own);
+        if (own) stage[have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned short)i;
+        have += __popcll(m);
+        base += 64;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int n = min(have, 64);
+      if (n == 0) break;
+      const bool active = lane < n;
+      const int i = active ? (int)stage[lane] : 0;
+      const int rest = lane + 64 < have ? (int)stage[lane + 64] : 0;  // (moved down below)
+      const int nt_i = active ? S.ntot[i] : 0;
+      const bool q_occupies = (nt_i & 0x40000000) != 0;
+      const int c_ntot = nt_i & 0xFFFF;
+      int b0 = 0, my_idx1 = 0;
+      if constexpr (mode_bucketed(MODE)) {
+        if (active) { b0 = A.q_b0[qbase + i]; my_idx1 = A.q_idx1[qbase + i]; }
+      }
+      uint32_t ck[MK], cj[MK];
+#pragma unroll
+      for (int k = 0; k < MK; k++) ck[k] = active ? S.lists[i * MK + k] : kNoCand;
+#pragma unroll
+      for (int k = 0; k < MK; k++) cj[k] = ck[k] != kNoCand ? cand_keypoint(ck[k], b0) : 0u;
+      // the query's component (the words' low bits no longer change)
+      const int root = active ? word_load<BIG>(&S.claim[cj[0]]) & kUfMask : 0;
+      __builtin_amdgcn_wave_barrier();
+      if (lane + 64 < have) stage[lane] = (unsigned short)rest;
+      have -= n;
       bool resolved = !active;
       while (true) {
+        const unsigned long long pending = __ballot(!resolved);
+        if (pending == 0) break;
+        // whose turn: the lowest pending lane of every component
+        if (!resolved) {
+          const int before = atomicMin(&S.claim[root], (lane << 20) | root);
+          // (global words: the loads below must not overtake the atomics, so their answers are waited for)
+          if constexpr (BIG) asm volatile("" ::"v"(before));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool mine = !resolved && (word_load<BIG>(&S.claim[root]) >> 20) == lane;
+        __builtin_amdgcn_wave_barrier();
+        if (mine) word_store<BIG>(&S.claim[root], kNoLane | root);
         // first and second candidate that are still free
         int s1 = -1, s2 = -1, d1 = 256, d2 = 256;
-        if (!resolved) {
-          bool need_rescan = false;
+        bool need_rescan = false;
+        if (mine) {
           int found = 0;
 #pragma unroll
           for (int k = 0; k < MK; k++) {
-            const int o_k = c.key[k] != 0xFFFFFFFFu ? (int)S.occ[c.idx[k]] : 1;
-            const bool avail_k = MODE == MODE_INIT ? (o_k == 0 || o_k - 1 > (int)(c.key[k] >> 20)) : o_k == 0;
-            if (c.key[k] != 0xFFFFFFFFu && avail_k) {
-              if (found == 0) { s1 = (int)c.idx[k]; d1 = (int)(c.key[k] >> 20); }
-              else if (found == 1) { s2 = (int)c.idx[k]; d2 = (int)(c.key[k] >> 20); }
+            const int o_k = ck[k] != kNoCand ? (int)S.occ[cj[k]] : 1;
+            const bool avail_k = MODE == MODE_INIT ? (o_k == 0 || o_k - 1 > (int)(ck[k] >> 16)) : o_k == 0;
+            if (ck[k] != kNoCand && avail_k) {
+              if (found == 0) { s1 = (int)cj[k]; d1 = (int)(ck[k] >> 16); }
+              else if (found == 1) { s2 = (int)cj[k]; d2 = (int)(ck[k] >> 16); }
               found++;
             }
           }
           const int want = (MODE == MODE_MAPPOINTS || MODE == MODE_BOW || MODE == MODE_INIT) ? 2 : 1;
-          // c.ntot > MK: candidates beyond the kept ones exist, so the list is not exhaustive
-          if (found < want && c.ntot > MK) need_rescan = true;
-          if (need_rescan) {
-            // the kept list ran out: scan again against the current occupancy
-            const float4 geo = A.q_geo[qbase + i];
-            const uint8_t* qp;
-            int b0 = 0, b1 = 0; float qx = 0.f, qy = 0.f;
-            if constexpr (mode_bucketed(MODE)) {
-              const int idx1 = A.q_idx1[qbase + i];
-              b0 = A.q_b0[qbase + i]; b1 = A.q_b1[qbase + i];
-              qx = A.q_x[qbase + idx1]; qy = A.q_y[qbase + idx1];
-              qp = A.q_desc + 32 * (qbase + idx1);
-            } else {
-              qp = A.q_desc + 32 * (qbase + i);
-            }
-            const uint4 e0 = reinterpret_cast<const uint4*>(qp)[0], e1 = reinterpret_cast<const uint4*>(qp)[1];
-            const uint32_t qd[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-            scan_query<MODE>(A, S, pair, nt, geo, qd, b0, b1, qx, qy, c);
+          // c_ntot > MK: candidates beyond the kept ones exist, so the list is not exhaustive
+          need_rescan = found < want && c_ntot > MK;
+        }
+        // A kept list that ran out: the query's candidates are scanned again, against the current
+        // occupancy - by the whole wavefront, one such query after the other.
+        for (unsigned long long rm = __ballot(need_rescan); rm; rm &= rm - 1) {  // uniform
+          const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)rm) - 1);
+          const int qi = __builtin_amdgcn_readlane(i, src);
+          const float4 geo = A.q_geo[qbase + qi];
+          const uint8_t* qp;
+          int b0 = 0, b1 = 0; float qx = 0.f, qy = 0.f;
+          if constexpr (mode_bucketed(MODE)) {
+            const int idx1 = A.q_idx1[qbase + qi];
+            b0 = A.q_b0[qbase + qi]; b1 = A.q_b1[qbase + qi];
+            qx = A.q_x[qbase + idx1]; qy = A.q_y[qbase + idx1];
+            qp = A.q_desc + 32 * (qbase + idx1);
+          } else {
+            qp = A.q_desc + 32 * (qbase + qi);
+          }
+          const uint4 e0 = reinterpret_cast<const uint4*>(qp)[0], e1 = reinterpret_cast<const uint4*>(qp)[1];
+          const uint32_t qd[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+          uint32_t rk[2], ri[2];
+          scan_query_wave<MODE>(A, S, geo, qd, b0, b1, qx, qy, rk, ri);
+          if (lane == src) {
             s1 = s2 = -1; d1 = d2 = 256;
-            if (c.key[0] != 0xFFFFFFFFu) { s1 = (int)c.idx[0]; d1 = (int)(c.key[0] >> 20); }
-            if (c.key[1] != 0xFFFFFFFFu) { s2 = (int)c.idx[1]; d2 = (int)(c.key[1] >> 20); }
+            if (rk[0] != kNoCand) { s1 = (int)ri[0]; d1 = (int)(rk[0] >> 16); }
+            if (rk[1] != kNoCand) { s2 = (int)ri[1]; d2 = (int)(rk[1] >> 16); }
           }
         }
-        // decision of this query if nothing before it in this step interferes
+        // the query's decision (everything before it in its component has been decided)
         bool accept = false, occupy = false;
-        if (!resolved && s1 >= 0) {
+        if (mine && s1 >= 0) {
           if constexpr (MODE == MODE_FRAMES) {
             accept = d1 <= TH_HIGH;
             occupy = accept && q_occupies;
@@ -719,26 +1089,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
             occupy = true;
           }
         }
-        // does an earlier unresolved query of this step take a slot this one looks at?
-        const unsigned long long pending = __ballot(!resolved);
-        if (pending == 0) break;
-        // claim[s] = lowest pending lane that would occupy s
-        if (occupy) {
-          const int before = atomicMin(&S.claim[s1], lane);
-          // (global claims: the loads below must not overtake the atomics, so their answers are waited for)
-          if constexpr (BIG) asm volatile("" ::"v"(before));
-        }
-        __builtin_amdgcn_wave_barrier();
-        bool conflict = false;
-        if (!resolved && s1 >= 0) {
-          conflict = word_load<BIG>(&S.claim[s1]) < lane;
-          if ((MODE == MODE_MAPPOINTS || MODE == MODE_BOW || MODE == MODE_INIT) && s2 >= 0) conflict = conflict || word_load<BIG>(&S.claim[s2]) < lane;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (occupy) word_store<BIG>(&S.claim[s1], 0x7FFFFFFF);
-        const unsigned long long cm = __ballot(conflict);
-        const int first_conf = cm ? (__ffsll((long long)cm) - 1) : 64;
-        if (!resolved && lane < first_conf) {
+        if (mine) {
           resolved = true;
           if (accept) {
             if constexpr (MODE == MODE_INIT) {
@@ -766,6 +1117,12 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       }
     }
   }
+  PT(4);
+#ifdef ORB_MATCH_PROFILE
+  if (pair == 0 && tid == 0)
+    printf("match profile (100 MHz ticks): setup+grid %lld  count+sort %lld  scan %lld  roots+share %lld  replay (wavefront 0) %lld\n",
+           pt[1] - pt[0], pt[6] - pt[1], pt[2] - pt[6], pt[3] - pt[2], pt[4] - pt[3]);
+#endif
   __syncthreads();
 
   // ---- phase C: rotation consistency (reference src/ORBmatcher.cc:1765-1785, 1014-1034,
@@ -815,10 +1172,11 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
 }
 
 size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds, bool desc_in_lds, bool owner = false) {
-  size_t n = sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + 2 * sizeof(float) * (size_t)max_t +
-             sizeof(unsigned short) * (size_t)((max_t + 1) & ~1) + 2 * (size_t)((max_t + 3) & ~3) +
+  // (with the queues' minimum; launch_match gives the queue what is left over)
+  size_t n = sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + sizeof(unsigned short) * kQueueMin * M_THREADS +
+             2 * sizeof(float) * (size_t)max_t + sizeof(uint32_t) * (size_t)max_t + 2 * (size_t)((max_t + 3) & ~3) +
              sizeof(int) * (size_t)max_t + 32;
-  if (lists_in_lds) n += (sizeof(uint2) * MK + sizeof(int)) * (size_t)max_q;
+  if (lists_in_lds) n += (sizeof(uint32_t) * MK + sizeof(int)) * (size_t)max_q;
   if (desc_in_lds) n += 32 * (size_t)max_t;
   if (owner) n += sizeof(int) * (size_t)max_t;
   return n;
@@ -826,10 +1184,10 @@ size_t match_lds_bytes(int max_t, int max_q, bool lists_in_lds, bool desc_in_lds
 
 // LDS of match_kernel<MODE, true> and the size of its per-pair block of global scratch
 size_t match_big_lds_bytes(int max_t) {
-  return sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + 2 * (size_t)((max_t + 3) & ~3) + 32;
+  return sizeof(int) * (GRID_COLS * GRID_ROWS + 4) + sizeof(unsigned short) * kQueueMin * M_THREADS + 2 * (size_t)((max_t + 3) & ~3) + 32;
 }
 size_t match_big_stride(int max_t) {
-  return ((4 * sizeof(int) + sizeof(unsigned short)) * (size_t)max_t + 2 + 255) & ~(size_t)255;
+  return (5 * sizeof(int) * (size_t)max_t + 255) & ~(size_t)255;
 }
 
 // ---------------------------------------------------------------------------
@@ -949,15 +1307,16 @@ constexpr size_t kScratchPerQuery = sizeof(uint2) * MK + sizeof(int) * 3 + sizeo
 void carve_scratch(MatchArgs& A, void* scratch, size_t nq) {
   unsigned char* p = reinterpret_cast<unsigned char*>(scratch);
   A.q_geo = reinterpret_cast<float4*>(p); p += sizeof(float4) * nq;
-  A.lists = reinterpret_cast<uint2*>(p); p += sizeof(uint2) * MK * nq;
+  A.lists = reinterpret_cast<uint32_t*>(p); p += sizeof(uint2) * MK * nq;  // (four bytes a candidate are in use)
   A.q_ntot = reinterpret_cast<int*>(p); p += sizeof(int) * nq;
   A.q_slot = reinterpret_cast<int*>(p); p += sizeof(int) * nq;
   A.q_bin = reinterpret_cast<int*>(p);
 }
 
 constexpr size_t kMatchLdsLimit = 156 * 1024;
+constexpr size_t kMatchLdsComfort = 96 * 1024;  // up to here the descriptors come along into LDS
 
-// true if the train side does not fit match_kernel's LDS-resident form (about 9000 keypoints; 7300
+// true if the train side does not fit match_kernel's LDS-resident form (about 7900 keypoints; 6500
 // for SearchForInitialization, which also keeps an owner per keypoint) and the call needs the
 // per-pair block of global scratch of the large form
 template <int MODE>
@@ -980,23 +1339,40 @@ int launch_match_as(const MatchArgs& A, int n_pairs, size_t lds, hipStream_t st)
   return ORBHIP_OK;
 }
 
+// The per-thread queues of the window scans: kQueueMin entries each are part of the sizes above;
+// up to kQueueMax where the LDS has room left.
+void give_queue_the_rest(MatchArgs& A, size_t& lds) {
+  const size_t one = sizeof(unsigned short) * M_THREADS;
+  const int extra = lds < kMatchLdsLimit ? (int)std::min<size_t>((kMatchLdsLimit - lds) / one, kQueueMax - kQueueMin) : 0;
+  A.queue_cap = kQueueMin + extra;
+  lds += one * extra;
+}
+
 template <int MODE>
 int launch_match(const MatchArgs& A0, int n_pairs, hipStream_t st) {
   MatchArgs A = A0;
+  A.queue_cap = kQueueMin;
   if (!A.keyframe_origin) { A.q_min_x = A.b.min_x; A.q_min_y = A.b.min_y; }
   else { A.q_min_x = (float)(int)A.b.min_x; A.q_min_y = (float)(int)A.b.min_y; }  // KeyFrame::mnMinX / mnMinY are const int
   constexpr bool own = MODE == MODE_INIT;
   if (match_needs_big<MODE>(A.max_t, A.max_q)) {
     if (!A.big) { set_error("too many train keypoints for the on-chip grid and no scratch for the large form was given"); return ORBHIP_ERR_CAPACITY; }
     A.desc_in_lds = 0; A.lists_in_lds = 0;
-    const size_t lds = match_big_lds_bytes(A.max_t);
+    size_t lds = match_big_lds_bytes(A.max_t);
     if (lds > kMatchLdsLimit) { set_error("too many train keypoints (limit 65535)"); return ORBHIP_ERR_UNSUPPORTED; }
+    give_queue_the_rest(A, lds);
     return launch_match_as<MODE, true>(A, n_pairs, lds, st);
   }
-  // descriptors first (every candidate reads them), then the ranked lists if there is room
-  A.desc_in_lds = match_lds_bytes(A.max_t, A.max_q, false, true, own) <= kMatchLdsLimit;
-  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, A.desc_in_lds != 0, own) <= kMatchLdsLimit;
-  const size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0, own);
+  // On chip beside the grid: the ranked lists, which the replay - one wavefront, every step a chain
+  // of dependent reads - walks in order; the train descriptors only where all of it stays small.
+  // A workgroup that fills the LDS keeps the blocks of every other kernel off its compute unit:
+  // with 148 KB here instead of 108, an extraction running beside a batch of 255 pairs took 4 %
+  // longer.  Descriptors read from global memory (they stay in L2) cost the ranking nothing
+  // measurable: the scans queue their candidates and take the distances in a loop of their own.
+  A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, false, own) <= kMatchLdsLimit;
+  A.desc_in_lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, true, own) <= kMatchLdsComfort;
+  size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0, own);
+  if (!mode_bucketed(MODE)) give_queue_the_rest(A, lds);
   return launch_match_as<MODE, false>(A, n_pairs, lds, st);
 }
 
@@ -1250,7 +1626,7 @@ static int frames_device_launch(int n_pairs, int max_last, int max_cur, const fl
     // more current-frame keypoints than the on-chip grid holds: the large form's block lies behind
     // the per-query arrays, if the caller sized the scratch with orb_match_scratch_bytes_for
     if (scratch_bytes < orb_match_scratch_bytes_for(n_pairs, max_last, max_cur)) {
-      set_error("max_cur = " + std::to_string(max_cur) + " keypoints do not fit the on-chip grid (about 9000): size the "
+      set_error("max_cur = " + std::to_string(max_cur) + " keypoints do not fit the on-chip grid (about 7900): size the "
                 "scratch with orb_match_scratch_bytes_for(n_pairs, max_last, max_cur)");
       return ORBHIP_ERR_CAPACITY;
     }
@@ -1306,7 +1682,7 @@ int orb_search_by_projection_frames_noalloc(int device_id, int n_pairs, int max_
     return ORBHIP_ERR_CAPACITY;
   }
   if (match_needs_big<MODE_FRAMES>(max_cur, max_last)) {
-    set_error("max_cur = " + std::to_string(max_cur) + " keypoints do not fit the on-chip grid (about 9000) and the large "
+    set_error("max_cur = " + std::to_string(max_cur) + " keypoints do not fit the on-chip grid (about 7900) and the large "
               "form needs scratch per frame pair; use orb_search_by_projection_frames_device");
     return ORBHIP_ERR_CAPACITY;
   }

@@ -13,7 +13,8 @@ from orb_slam2_amd._lib import FrameBounds, check
 
 L = _lib.lib()
 dev = torch.device("cuda", 0)
-for npairs, n in [(1, 2000), (1, 4000), (1, 8000), (16, 2000), (255, 2000)]:
+# usage: match_kernel_time.py [pairs ...]      default: 1 and 255 pairs of 2000 keypoints
+for npairs, n in [(int(a), 2000) for a in sys.argv[1:]] or [(1, 2000), (255, 2000)]:
     host, sc = _inputs(np.random.default_rng(1), npairs, n, n, [n] * npairs, [n] * npairs)
     d = {k: torch.from_numpy(v).to(dev) for k, v in host.items()}
     K, sf, bounds = sc["K"], sc["sf"], FrameBounds(*sc["bounds"])
