@@ -187,15 +187,8 @@ def main():
     chain.load(seq)  # uploads the frames, extracts once, builds every frame's map points and the pair poses
     ex, max_kp, npairs = chain.ex, chain.max_kp, chain.npairs
     d_nout, d_nm = chain.nout[0], chain.d_nm
-    pr = os.environ.get("ORBHIP_BENCH_PRIO", "")
-    if pr:
-        pe, pm = [int(v) for v in pr.split(",")]
-        s_ex = torch.cuda.Stream(device=dev, priority=pe)
-        s_m = torch.cuda.Stream(device=dev, priority=pm)
-        sys.stderr.write("stream priorities: extraction %d matcher %d\n" % (s_ex.priority, s_m.priority))
-    else:
-      s_ex = torch.cuda.current_stream()
-      s_m = torch.cuda.Stream(device=dev) if args.overlap else s_ex
+    s_ex = torch.cuda.current_stream()
+    s_m = torch.cuda.Stream(device=dev) if args.overlap else s_ex
     stream = s_ex.cuda_stream
 
     def extract(s=0):

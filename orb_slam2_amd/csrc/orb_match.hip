@@ -429,21 +429,15 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
     // insertion) as soon as ONE of its 64 lanes has a survivor.
     const int qcap = A.queue_cap;
     unsigned short* const queue = S.queue + threadIdx.x;  // entry k at queue[k * M_THREADS]
+    // the level range as two bounds every octave (0..255) can be compared with
+    const int lo = bCheckLevels ? max(minLevel, 0) : 0;
+    const int hi = bCheckLevels && maxLevel >= 0 ? min(maxLevel, 255) : 255;
     int ix = nMinCellX;
     int p = S.start[ix * GRID_ROWS + nMinCellY], pe = S.start[ix * GRID_ROWS + nMaxCellY + 1];
     bool more = true;
-#ifdef ORB_MATCH_PROFILE
-    long long pf_fill = 0, pf_drain = 0; int pf_nf = 0, pf_nd = 0, pf_outer = 0;
-#endif
     while (more) {
       int n = 0;
-#ifdef ORB_MATCH_PROFILE
-      long long tq = wall_clock64(); pf_outer++;
-#endif
-      while (true) {
-#ifdef ORB_MATCH_PROFILE
-        pf_nf++;
-#endif
+      for (;;) {
         if (p >= pe) {
           if (++ix > nMaxCellX) { more = false; break; }
           p = S.start[ix * GRID_ROWS + nMinCellY]; pe = S.start[ix * GRID_ROWS + nMaxCellY + 1];
@@ -452,59 +446,49 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
         const float2 xy = S.gxy[p];
         const uint32_t meta = S.gmeta[p];
         const int slot = p++;
-        if (!(fabsf(xy.x - x) < r && fabsf(xy.y - y) < r)) continue;
         const int oct = (int)((meta >> 16) & 0xFFu);
-        if (bCheckLevels) {
-          if (oct < minLevel) continue;
-          if (maxLevel >= 0 && oct > maxLevel) continue;
-        }
-        // this scan runs before anything is decided: the occupancy is the initial one, held in the word
-        if (MODE != MODE_INIT && (meta >> 24)) continue;
+        // window, level, and the occupancy before anything is decided (held in the word): tested
+        // without branches, the wavefront's lanes differ at nearly every item
+        bool ok = ((int)(fabsf(xy.x - x) < r) & (int)(fabsf(xy.y - y) < r) & (int)(oct >= lo) & (int)(oct <= hi)) != 0;
+        if (MODE != MODE_INIT) ok &= meta < 0x1000000u;
         if constexpr (MODE == MODE_BEST) {
-          if (A.chi2 > 0) {  // reference src/ORBmatcher.cc:1158-1164
+          if (ok && A.chi2 > 0) {  // reference src/ORBmatcher.cc:1158-1164
             const float ex = x - xy.x, ey = y - xy.y;
             const float e2 = ex * ex + ey * ey;
-            if ((double)(e2 * A.sigma2[min(oct, kMaxLevels - 1)]) > A.chi2) continue;
+            if ((double)(e2 * A.sigma2[min(oct, kMaxLevels - 1)]) > A.chi2) ok = false;
           }
         }
-        queue[n * M_THREADS] = (unsigned short)slot;
-        if (++n == qcap) break;
+        if (ok) queue[n * M_THREADS] = (unsigned short)slot;
+        n += ok;
+        if (n == qcap) break;
       }
-#ifdef ORB_MATCH_PROFILE
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      pf_fill += wall_clock64() - tq; tq = wall_clock64();
-#endif
+      // the queued items' distances; the next one's descriptor is on its way while one is ranked
+      uint32_t slot = 0, meta = 0;
+      uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
+      auto load = [&](int k) {
+        slot = queue[k * M_THREADS];
+        meta = S.gmeta[slot];
+        const uint32_t j = meta & 0xFFFFu;
+        t0 = tdesc[2 * j]; t1 = tdesc[2 * j + 1];
+      };
+      if (n > 0) load(0);
       for (int k = 0; k < n; k++) {
-#ifdef ORB_MATCH_PROFILE
-        pf_nd++;
-#endif
-        const uint32_t slot = queue[k * M_THREADS];
-        const uint32_t meta = S.gmeta[slot];
-        const int j = (int)(meta & 0xFFFFu);
-        const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+        const uint32_t c_slot = slot, c_meta = meta;
+        const uint4 c0 = t0, c1 = t1;
+        if (k + 1 < n) load(k + 1);
+        const int j = (int)(c_meta & 0xFFFFu);
+        const int d = hamming256(qd, c0, c1);
         if constexpr (MODE == MODE_INIT) {
           // occ = matched distance + 1 (0 = never matched): skip if vMatchedDistance[i2] <= dist
           // (reference src/ORBmatcher.cc:596)
-          const int occ = (int)(meta >> 24);
+          const int occ = (int)(c_meta >> 24);
           if (occ && occ - 1 <= d) continue;
         }
         if (d > dcap) continue;
         unite(j);
-        cand_insert(c, ((uint32_t)d << 16) | slot);
+        cand_insert(c, ((uint32_t)d << 16) | c_slot);
       }
-#ifdef ORB_MATCH_PROFILE
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      pf_drain += wall_clock64() - tq;
-#endif
     }
-#ifdef ORB_MATCH_PROFILE_SCAN
-    if (UNITE && pair == 0) {
-      int mf = pf_nf, md = pf_nd, mo = pf_outer; long long mfill = pf_fill, mdr = pf_drain;
-      for (int o = 32; o >= 1; o >>= 1) { mf = max(mf, __shfl_xor(mf, o)); md = max(md, __shfl_xor(md, o)); mo = max(mo, __shfl_xor(mo, o));
-        mfill = max(mfill, __shfl_xor(mfill, o)); mdr = max(mdr, __shfl_xor(mdr, o)); }
-      if (threadIdx.x == 0) printf("scan wave 0: fill %lld (max lane iters %d) drain %lld (max lane items %d) outer %d qcap %d\n", mfill, mf, mdr, md, mo, qcap);
-    }
-#endif
     (void)nt;
   } else {
     // candidates: keyframe-2 features of the same vocabulary node, in order; the
@@ -942,8 +926,13 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   // count, bit 30 the observation flag, a negative word an inactive query).
   constexpr int kWaves = M_THREADS / 64;
   static_assert(kWaves == 16, "four bits of the count word name the wavefront");
+  // (count words in global memory are written by one thread and read by another several times over:
+  // past the vector cache, which may still hold an older value)
+  auto count_word = [&](int i) -> int {
+    return A.lists_in_lds ? S.ntot[i] : __hip_atomic_load(&S.ntot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   for (int i = tid; i < nq; i += M_THREADS) {
-    const int w = S.ntot[i];
+    const int w = count_word(i);
     const uint32_t first = S.lists[i * MK];
     if (w > 0 && (w & 0xFFFF) > 0 && first != kNoCand) {
       int b0 = 0;
@@ -971,7 +960,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     for (;;) {
       while (have < 64 && base < nq) {  // (wavefront-uniform)
         const int i = base + lane;
-        const int w = i < nq ? S.ntot[i] : -1;
+        const int w = i < nq ? count_word(i) : -1;
         const bool own = w > 0 && (w & 0xFFFF) > 0 && ((w >> 24) & (kWaves - 1)) == wave;
         const unsigned long long m = __ballot(own);
         if (own) stage[have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned short)i;
@@ -984,7 +973,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       const bool active = lane < n;
       const int i = active ? (int)stage[lane] : 0;
       const int rest = lane + 64 < have ? (int)stage[lane + 64] : 0;  // (moved down below)
-      const int nt_i = active ? S.ntot[i] : 0;
+      const int nt_i = active ? count_word(i) : 0;
       const bool q_occupies = (nt_i & 0x40000000) != 0;
       const int c_ntot = nt_i & 0xFFFF;
       int b0 = 0, my_idx1 = 0;

@@ -101,6 +101,44 @@ def test_search_by_projection_frames_batch(oracle):
         assert np.array_equal(match[p, :curs[p].N], wants[p][1])
 
 
+@pytest.mark.parametrize("seed,nl,nc,spread", [(0, 1500, 1200, 30.0), (1, 2000, 700, 12.0), (2, 900, 2000, 60.0)])
+def test_search_by_projection_frames_in_one_crowded_corner(oracle, seed, nl, nc, spread):
+    """Every current keypoint in one small patch, on one level, with descriptors a few bits apart:
+    every map point reaches most of them, so all queries hang together in ONE chain of conflicts
+    (one wavefront replays it while the others have nothing), kept lists run out and windows are
+    scanned again, and equal distances are decided by the visiting order."""
+    from orb_slam2_amd import Frame, MapPoint, ORBmatcher
+    rng = np.random.default_rng(seed)
+    sc = projection_scene(rng, nl, nc, 376, 1241)
+    Cu, L = sc["cur"], sc["last"]
+    Cu["x"][:] = (600 + rng.uniform(-spread, spread, nc)).astype(np.float32)
+    Cu["y"][:] = (180 + rng.uniform(-spread, spread, nc)).astype(np.float32)
+    Cu["octave"][:] = 2
+    Cu["desc"][:] = flip_bits(rng, np.repeat(Cu["desc"][:1], nc, 0), 10)
+    Cu["obs"][:] = -1
+    Cu["angle"][:] = (40 + rng.normal(0, 3, nc)).astype(np.float32)
+    L["angle"][:] = (55 + rng.normal(0, 3, nl)).astype(np.float32)
+    fx, fy, cx, cy = sc["K"]
+    depth = rng.uniform(4, 30, nl).astype(np.float32)
+    u = (600 + rng.uniform(-spread, spread, nl)).astype(np.float32)
+    v = (180 + rng.uniform(-spread, spread, nl)).astype(np.float32)
+    Xc = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], 1).astype(np.float32)
+    L["xw"][:] = (Xc - sc["Tcw"][:3, 3][None]).astype(np.float32)
+    L["octave"][:] = rng.integers(1, 4, nl)
+    L["mp_desc"][:] = flip_bits(rng, np.repeat(Cu["desc"][:1], nl, 0), 10)
+    L["mp_obs"][:] = rng.integers(0, 3, nl)
+    want_n, want_match = oracle.search_by_projection_frames(sc["Tcw"], sc["K"], sc["bounds"], sc["sf"], L, Cu, 7.0, True)
+    assert want_n > min(nl, nc) // 2
+    sf, s2 = scale_tables()
+    last = Frame(kp_struct(np.zeros(nl), np.zeros(nl), L["octave"], L["angle"]), np.zeros((nl, 32), np.uint8), sf, s2,
+                 sc["K"], sc["bounds"])
+    for i in range(nl):
+        last.mvpMapPoints[i] = MapPoint(L["xw"][i], L["mp_desc"][i], L["mp_obs"][i])
+    cur = Frame(kp_struct(Cu["x"], Cu["y"], Cu["octave"], Cu["angle"]), Cu["desc"], sf, s2, sc["K"], sc["bounds"], sc["Tcw"])
+    nm, match = ORBmatcher(0.9, True).search_by_projection_frames_batch([cur], [last], 7.0)
+    assert nm[0] == want_n and np.array_equal(match[0, :nc], want_match)
+
+
 @pytest.mark.parametrize("seed,nmp,nf,th,ratio", [(0, 500, 800, 1.0, 0.8), (1, 3000, 2000, 5.0, 0.8), (2, 2000, 600, 3.0, 0.6)])
 def test_search_by_projection_mappoints(oracle, seed, nmp, nf, th, ratio):
     from orb_slam2_amd import Frame, MapPoint, ORBmatcher
