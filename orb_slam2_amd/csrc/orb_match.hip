@@ -493,11 +493,20 @@ __device__ void scan_query(const MatchArgs& A, const MatchShared& S, int pair, i
   } else {
     // candidates: keyframe-2 features of the same vocabulary node, in order; the
     // reference keeps the LAST one among equal distances ('dist > bestDist' skips)
+    // (the bucket's items and their descriptors come from global memory, one after the other: the
+    // item two ahead and the descriptor one ahead are on their way while a distance is taken)
     int pos = 0;
+    int j_next = bucket0 < bucket1 ? A.items2[bucket0] : 0;
+    int j_after = bucket0 + 1 < bucket1 ? A.items2[bucket0 + 1] : 0;
+    uint4 t0 = tdesc[2 * j_next], t1 = tdesc[2 * j_next + 1];
     for (int p = bucket0; p < bucket1; p++, pos++) {
-      const int j = A.items2[p];
+      const int j = j_next;
+      const uint4 c0 = t0, c1 = t1;
+      j_next = j_after;
+      if (p + 1 < bucket1) { t0 = tdesc[2 * j_next]; t1 = tdesc[2 * j_next + 1]; }
+      j_after = p + 2 < bucket1 ? A.items2[p + 2] : 0;
       if (S.occ[j]) continue;
-      const int d = hamming256(qd, tdesc[2 * j], tdesc[2 * j + 1]);
+      const int d = hamming256(qd, c0, c1);
       if constexpr (MODE == MODE_BOW) {
         // SearchByBoW keeps best and second over the whole bucket; the first minimum wins
         if (d > dcap) continue;
@@ -1304,6 +1313,7 @@ void carve_scratch(MatchArgs& A, void* scratch, size_t nq) {
 
 constexpr size_t kMatchLdsLimit = 156 * 1024;
 constexpr size_t kMatchLdsComfort = 96 * 1024;  // up to here the descriptors come along into LDS
+constexpr int kFewPairs = 16;
 
 // true if the train side does not fit match_kernel's LDS-resident form (about 7900 keypoints; 6500
 // for SearchForInitialization, which also keeps an owner per keypoint) and the call needs the
@@ -1352,14 +1362,17 @@ int launch_match(const MatchArgs& A0, int n_pairs, hipStream_t st) {
     give_queue_the_rest(A, lds);
     return launch_match_as<MODE, true>(A, n_pairs, lds, st);
   }
-  // On chip beside the grid: the ranked lists, which the replay - one wavefront, every step a chain
-  // of dependent reads - walks in order; the train descriptors only where all of it stays small.
-  // A workgroup that fills the LDS keeps the blocks of every other kernel off its compute unit:
-  // with 148 KB here instead of 108, an extraction running beside a batch of 255 pairs took 4 %
-  // longer.  Descriptors read from global memory (they stay in L2) cost the ranking nothing
-  // measurable: the scans queue their candidates and take the distances in a loop of their own.
+  // On chip beside the grid: the ranked lists, which the replay - every step a chain of dependent
+  // reads - walks in order.  The train descriptors only for the vocabulary-bucket searches, which
+  // take a distance to every item of a bucket: a window search takes two or three per query, less
+  // than staging the descriptors costs (one pair of 2000 x 2000: 0.093 ms staged, 0.076 ms from
+  // global memory, where they stay in L2).  And a workgroup that fills the LDS keeps the blocks of
+  // every other kernel off its compute unit - an extraction beside a batch of 255 pairs took 4 %
+  // longer with 148 KB here than with 108 - so batches stage descriptors only while all of it
+  // stays small; a call for a few pairs holds few compute units and may fill the LDS.
   A.lists_in_lds = match_lds_bytes(A.max_t, A.max_q, true, false, own) <= kMatchLdsLimit;
-  A.desc_in_lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, true, own) <= kMatchLdsComfort;
+  A.desc_in_lds = mode_bucketed(MODE) && match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, true, own) <=
+                                             (n_pairs <= kFewPairs ? kMatchLdsLimit : kMatchLdsComfort);
   size_t lds = match_lds_bytes(A.max_t, A.max_q, A.lists_in_lds != 0, A.desc_in_lds != 0, own);
   if (!mode_bucketed(MODE)) give_queue_the_rest(A, lds);
   return launch_match_as<MODE, false>(A, n_pairs, lds, st);
