@@ -254,7 +254,6 @@ constexpr int kSmallBatchFrames = 8;               // up to this many frames a l
 constexpr int kFewFrames = 4;                       // up to this many frames FAST takes shorter runs of cells
 constexpr int kPipeMinFrames = 64;                  // host-buffer batches from this size on go through in pieces
 constexpr int kPipePieces = 8;                      // ... at most this many
-constexpr int kDualFromLevelInBatches = 6;         // batches: pyramid levels from here on go two to a launch
 constexpr int kSplitMinFrames = 64;                 // device-buffer batches from this size on run as two staggered halves
 constexpr int kGraphMaxFrames = 8;                 // batches up to this size replay a captured graph
 constexpr int kPoolThreads = 12;                   // host threads that pack a large batch (the caller is one)
@@ -646,9 +645,8 @@ int enqueue(OrbExtractor* h, int nframes, const uint8_t* d_images, size_t stride
   else launch_pyr_level0_color(c_img, stride, frame_stride, h->channels, h->rgb_order, h->gray, c_pyr, P, c_cnt, cn, st);
   for (int l = fused01 ? 2 : 1; l < P.nlevels; l++) {
     const OrbExtractor::TileInfo& ti = h->tile[l];
-    // (batches: only the smallest levels, whose launches are too short to fill the GPU - levels 6 and 7
-    // together take 0.8 % off a 256-frame step, from level 4 or 2 on the step is slower)
-    if ((nframes <= kSmallBatchFrames || l >= kDualFromLevelInBatches) && h->pair[l].ok) {
+    // (batches: levels 5 + 6, or 3 + 4 and 5 + 6, in one launch each make a 256-frame step 0.7 % and 1.5 % slower)
+    if (nframes <= kSmallBatchFrames && h->pair[l].ok) {
       const OrbExtractor::TileInfo& t2 = h->tile[l + 1];
       const OrbExtractor::PairInfo& pi = h->pair[l];
       launch_pyr_resize_dual(c_pyr, P, l, h->d_xtp + ti.xtp_off, h->d_xtp + t2.xtp_off, h->d_ytab,
@@ -882,7 +880,7 @@ int orb_extract_batch_device(OrbExtractor* h, int n_frames, const uint8_t* d_ima
       ORB_HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
       ORB_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     }
-    const int n1 = n_frames / 2, n2 = n_frames - n1;
+    const int n1 = n_frames / 2, n2 = n_frames - n1;  // (a quarter, three eighths, five eighths first: none is faster)
     // the second half starts after whatever precedes this call on the caller's stream ...
     ORB_HIP_CHECK(hipEventRecord(h->ev_fork, st));
     ORB_HIP_CHECK(hipStreamWaitEvent(h->half, h->ev_fork, 0));
