@@ -682,8 +682,11 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   }
   const size_t tbase = (size_t)pair * A.max_t, qbase = (size_t)pair * A.max_q;
   int* out_match = A.out_match + (mode_out_by_query(MODE) ? qbase : tbase);
+  // Development build (make EXTRA=-DORB_MATCH_PROFILE OUT=...): pair 0 prints the phases' durations in
+  // ticks of the 100 MHz wall clock.  PT(k) stamps: 0 start, 1 grid built, 5 queries binned, 2 ranked,
+  // 3 components shared out, 4 replayed.
 #ifdef ORB_MATCH_PROFILE
-  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long pt[6] = {0, 0, 0, 0, 0, 0};
 #define PT(k) pt[k] = wall_clock64()
 #else
 #define PT(k)
@@ -868,9 +871,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
     if (scan) __hip_atomic_store(&order[atomicAdd(&s_bins[kWorkBins - 1 - min(work, kWorkBins - 1)], 1)], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-#ifdef ORB_MATCH_PROFILE
-  PT(6);
-#endif
+  PT(5);
   for (;;) {
     // A wavefront takes the next 64 queries of the order when it is done with its last ones: the
     // longest first, so the wavefronts end about together.  (Every lane reads the chunk's number
@@ -962,26 +963,30 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
   // do not touch each other's keypoints, go side by side - in the step and across the wavefronts.
   {
     const int lane = tid & 63, wave = tid >> 6;
-    // gathered queries, up to 63 left over + 64 new: in the scans' queues, which are idle now
-    static_assert(kQueueMin * M_THREADS >= 128 * kWaves, "the queues' minimum holds every wavefront's gathered queries");
-    unsigned short* const stage = S.queue + 128 * wave;
-    int have = 0, base = 0;
+    // the (up to 64) queries gathered for a step: in the scans' queues, which are idle now
+    static_assert(kQueueMin * M_THREADS * sizeof(unsigned short) >= 64 * kWaves * sizeof(int), "the queues' minimum holds every wavefront's gathered queries");
+    int* const stage = reinterpret_cast<int*>(S.queue) + 64 * wave;
+    int base = 0;
+    unsigned long long taken = 0;  // lanes of the 64 queries at `base` that an earlier step has taken
     for (;;) {
+      int have = 0;
       while (have < 64 && base < nq) {  // (wavefront-uniform)
         const int i = base + lane;
         const int w = i < nq ? count_word(i) : -1;
-        const bool own = w > 0 && (w & 0xFFFF) > 0 && ((w >> 24) & (kWaves - 1)) == wave;
+        const bool own = w > 0 && (w & 0xFFFF) > 0 && ((w >> 24) & (kWaves - 1)) == wave && !((taken >> lane) & 1);
         const unsigned long long m = __ballot(own);
-        if (own) stage[have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned short)i;
-        have += __popcll(m);
-        base += 64;
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const bool take = own && have + rank < 64;
+        if (take) stage[have + rank] = i;
+        if (have + __popcll(m) <= 64) { have += __popcll(m); base += 64; taken = 0; }
+        else { taken |= __ballot(take); have = 64; }  // the rest of these 64 in the next step
       }
       __builtin_amdgcn_wave_barrier();
-      const int n = min(have, 64);
+      const int n = have;
       if (n == 0) break;
       const bool active = lane < n;
-      const int i = active ? (int)stage[lane] : 0;
-      const int rest = lane + 64 < have ? (int)stage[lane + 64] : 0;  // (moved down below)
+      const int i = active ? stage[lane] : 0;
+      __builtin_amdgcn_wave_barrier();
       const int nt_i = active ? count_word(i) : 0;
       const bool q_occupies = (nt_i & 0x40000000) != 0;
       const int c_ntot = nt_i & 0xFFFF;
@@ -996,9 +1001,6 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
       for (int k = 0; k < MK; k++) cj[k] = ck[k] != kNoCand ? cand_keypoint(ck[k], b0) : 0u;
       // the query's component (the words' low bits no longer change)
       const int root = active ? word_load<BIG>(&S.claim[cj[0]]) & kUfMask : 0;
-      __builtin_amdgcn_wave_barrier();
-      if (lane + 64 < have) stage[lane] = (unsigned short)rest;
-      have -= n;
       bool resolved = !active;
       while (true) {
         const unsigned long long pending = __ballot(!resolved);
@@ -1119,7 +1121,7 @@ __global__ __launch_bounds__(M_THREADS) void match_kernel(MatchArgs A) {
 #ifdef ORB_MATCH_PROFILE
   if (pair == 0 && tid == 0)
     printf("match profile (100 MHz ticks): setup+grid %lld  count+sort %lld  scan %lld  roots+share %lld  replay (wavefront 0) %lld\n",
-           pt[1] - pt[0], pt[6] - pt[1], pt[2] - pt[6], pt[3] - pt[2], pt[4] - pt[3]);
+           pt[1] - pt[0], pt[5] - pt[1], pt[2] - pt[5], pt[3] - pt[2], pt[4] - pt[3]);
 #endif
   __syncthreads();
 

@@ -61,7 +61,7 @@ def _projection_case(oracle, seed, nl, nc, clusters, ori=True):
             cur.mvpMapPoints[i2] = MapPoint(np.zeros(3), np.zeros(32, np.uint8), Cu["obs"][i2])
     nm, match = ORBmatcher(0.9, ori).search_by_projection_frames_batch([cur], [last], 7.0)
     assert nm[0] == want_n and np.array_equal(match[0, :nc], want_match)
-    assert want_n > nl // 10
+    assert want_n > min(nl, nc) // 10
     return sc, want_n, want_match
 
 
@@ -83,7 +83,7 @@ def _first_size_of_the_large_form(nl):
 
 
 @pytest.mark.parametrize("nl,nc,clusters", [(4000, 4000, 30), (8000, 8000, 60), (8000, 12000, 200), (3000, 30000, 0),
-                                             (500, 65535, 0)])
+                                             (500, 65535, 0), (70000, 3000, 40)])  # (the last: more queries than 16 bits count)
 def test_search_by_projection_at_and_beyond_the_shipped_size(oracle, nl, nc, clusters):
     _projection_case(oracle, 1000 + nc, nl, nc, clusters)
 
