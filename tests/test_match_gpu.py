@@ -128,7 +128,7 @@ def test_search_by_projection_frames_in_one_crowded_corner(oracle, seed, nl, nc,
     L["mp_desc"][:] = flip_bits(rng, np.repeat(Cu["desc"][:1], nl, 0), 10)
     L["mp_obs"][:] = rng.integers(0, 3, nl)
     want_n, want_match = oracle.search_by_projection_frames(sc["Tcw"], sc["K"], sc["bounds"], sc["sf"], L, Cu, 7.0, True)
-    assert want_n > min(nl, nc) // 2
+    assert want_n > min(nl, nc) // 2, "scene too poor"
     sf, s2 = scale_tables()
     last = Frame(kp_struct(np.zeros(nl), np.zeros(nl), L["octave"], L["angle"]), np.zeros((nl, 32), np.uint8), sf, s2,
                  sc["K"], sc["bounds"])

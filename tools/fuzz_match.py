@@ -33,6 +33,7 @@ for r in range(n_rounds):
     s = int(rng.integers(0, 1 << 30))
     ri = lambda a, b: int(rng.integers(a, b))
     run("frames", T.test_search_by_projection_frames, s, ri(50, 3000), ri(50, 3000), ri(0, 40), bool(ri(0, 2)))
+    run("corner", T.test_search_by_projection_frames_in_one_crowded_corner, s, ri(200, 3000), ri(200, 3000), float(rng.uniform(8, 80)))
     run("mappoints", T.test_search_by_projection_mappoints, s, ri(50, 3000), ri(50, 2500), float(rng.choice([1.0, 3.0, 5.0])), float(rng.uniform(0.5, 0.95)))
     run("triang", T.test_search_for_triangulation, s, ri(100, 2500), ri(100, 2500), bool(ri(0, 2)))
     run("windowed", T.test_match_windowed_vs_oracle, s, ri(100, 3000), ri(100, 3500), int(rng.choice([50, 100])), bool(ri(0, 2)))
