@@ -112,6 +112,14 @@ def main():
     ap.add_argument("--overlap", type=int, default=1,
                     help="1: the matcher of step k runs on a second stream beside the extraction of step k+1 "
                          "(two sets of keypoint buffers); 0: one stream")
+    ap.add_argument("--handles", type=int, default=1,
+                    help="extractor handles that take the steps in turn, each on a stream of its own, so that step "
+                         "k + 1 starts beside the end of step k (with --overlap 1; every handle holds its own pyramid "
+                         "and work buffers).  2 is 1.3 %% faster over 80 steps and no faster over 20")
+    ap.add_argument("--spinup-ms", type=float, default=100.0,
+                    help="untimed steps are run for this long before the W warm-up steps: after the host-side set-up "
+                         "the GPU takes tens of milliseconds of load to reach its steady state (20 steps after 5 "
+                         "warm-up steps alone read 2 %% slower than after 60)")
     ap.add_argument("--split", type=int, default=1,
                     help="1: orb_extract_batch_device runs the batch as two staggered halves (its default); 0: on the "
                          "caller's stream alone")
@@ -181,18 +189,19 @@ def main():
     seq = synth_sequence(ROWS, COLS, B, seed=1000 + rank, step=2)
     # two sets of extractor outputs: with --overlap the matcher reads one while the next step fills the other
     nsets = 2 if args.overlap else 1
+    n_handles = max(1, min(args.handles, nsets)) if args.overlap else 1
     chain = DeviceChain(ROWS, COLS, B, nfeatures=NFEAT, nlevels=NLEVELS, device=local, nsets=nsets, th=7.0,
-                        check_orientation=True)
-    check(L.orb_extractor_set_batch_split(chain.ex._h, args.split))
+                        check_orientation=True, n_handles=n_handles)
+    for e in chain.exs:
+        check(L.orb_extractor_set_batch_split(e._h, args.split))
     chain.load(seq)  # uploads the frames, extracts once, builds every frame's map points and the pair poses
     ex, max_kp, npairs = chain.ex, chain.max_kp, chain.npairs
     d_nout, d_nm = chain.nout[0], chain.d_nm
     s_ex = torch.cuda.current_stream()
     s_m = torch.cuda.Stream(device=dev) if args.overlap else s_ex
     stream = s_ex.cuda_stream
-
-    def extract(s=0):
-        chain.extract(s, s_ex.cuda_stream)
+    # extraction streams, one per handle
+    s_exs = [s_ex] + [torch.cuda.Stream(device=dev) for _ in range(n_handles - 1)]
 
     def match(s=0):
         chain.match(s, s_m.cuda_stream)
@@ -201,14 +210,16 @@ def main():
     m_done = [torch.cuda.Event() for _ in range(nsets)]
 
     def step(k, ev_a=None, ev_b=None):
-        """Extraction of step k on s_ex, its matching on s_m; set k % nsets is refilled only after the
-        matcher of step k - nsets has read it.  With one stream the waits are no-ops."""
-        s = k % nsets
+        """Extraction of step k by handle k % n_handles on that handle's stream, its matching on s_m; set
+        k % nsets is refilled only after the matcher of step k - nsets has read it.  With one stream the
+        waits are no-ops."""
+        s, hd = k % nsets, k % n_handles
+        se = s_exs[hd]
         if args.overlap and k >= nsets:
-            s_ex.wait_event(m_done[s])
-        extract(s)
+            se.wait_event(m_done[s])
+        chain.extract(s, se.cuda_stream, handle=hd)
         if args.overlap:
-            ex_done[s].record(s_ex)
+            ex_done[s].record(se)
             s_m.wait_event(ex_done[s])
         if ev_a is not None:
             ev_a.record(s_m)
@@ -219,8 +230,17 @@ def main():
             m_done[s].record(s_m)
 
     # ---------------- timed region ----------------
+    k0 = 0
+    if args.spinup_ms > 0:
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            for _ in range(4):
+                step(k0)
+                k0 += 1
+            torch.cuda.synchronize()
+        k0 += (-k0) % (nsets * n_handles)  # (the steps below start at set 0, handle 0 again)
     for k in range(args.warmup):
-        step(k)
+        step(k0 + k)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -524,7 +544,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "KITTI-shaped 1241x376 sequence, 2000 features, 8 levels, scale 1.2, FAST 20/7; "
                                    "extract + frame-to-frame SearchByProjection(th=7)",
-                       "frames_per_gpu_per_step": B, "streams": 2 if args.overlap else 1,
+                       "frames_per_gpu_per_step": B,
+                       "streams": (n_handles * (2 if args.split and B >= 64 else 1) + 1) if args.overlap else 1,
+                       "extractor_handles": n_handles, "spinup_ms": args.spinup_ms,
                        "batch_split": bool(args.split and B >= 64), "pairs_per_gpu_per_step": npairs,
                        "keypoints_per_frame": round(nkp / B, 1), "matches_per_pair": round(nmatch / npairs, 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(gbs[dom], 1), "peak": HBM_PEAK_GBS,

@@ -14,13 +14,16 @@ from .synth import SequenceScene
 
 class DeviceChain:
     def __init__(self, rows, cols, n_frames, nfeatures=2000, nlevels=8, device=0, nsets=1, th=7.0,
-                 check_orientation=True):
+                 check_orientation=True, n_handles=1):
         import torch
         self.torch = torch
         self.rows, self.cols, self.B, self.local = int(rows), int(cols), int(n_frames), int(device)
         self.dev = torch.device("cuda", self.local)
         self.L = _lib.lib()
-        self.ex = ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=self.local)
+        # n_handles extractor handles: a handle serves one stream at a time, so batches that are to be
+        # in flight together (step k + 1 beside step k) take one each
+        self.exs = [ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=self.local) for _ in range(max(1, n_handles))]
+        self.ex = self.exs[0]
         self.nlevels = nlevels
         self.max_kp = self.ex.max_keypoints(rows, cols)
         self.scene = SequenceScene(rows, cols)
@@ -67,9 +70,9 @@ class DeviceChain:
         self.d_last_obs = torch.from_numpy(obs).to(self.dev)
         self.d_tcw = torch.from_numpy(tcw).to(self.dev)
 
-    def extract(self, s=0, stream=None):
+    def extract(self, s=0, stream=None, handle=0):
         st = self.torch.cuda.current_stream().cuda_stream if stream is None else stream
-        self.ex.extract_batch_device(self.d_img.data_ptr(), self.B, self.rows, self.cols, self.kps[s].data_ptr(),
+        self.exs[handle].extract_batch_device(self.d_img.data_ptr(), self.B, self.rows, self.cols, self.kps[s].data_ptr(),
                                      self.desc[s].data_ptr(), self.nout[s].data_ptr(), self.max_kp, stream=st)
 
     def match(self, s=0, stream=None):
