@@ -9,7 +9,8 @@ tag, src = sys.argv[1], sys.argv[2]
 import os
 for sub, name, head in [
         ('stats', 'kernel_stats', "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-frames 0 --host-reps 0 --knn-reps 3 --split 0 --overlap 0 "
-         "(every kernel alone on the GPU, 256 frames per launch: the times bench.py's roofline is computed from; 1M x 1M kNN-2: "
+         "(every kernel alone on the GPU, 256 frames per launch: the times bench.py's roofline is computed from; the calls include "
+         "the benchmark's 100 ms of untimed spin-up steps; 1M x 1M kNN-2: "
          "knn2_mfma_kernel x3 + warm-ups, knn2_kernel x1; MI355X). pyr_level01_kernel makes levels 0 and 1, pyr_resize_tile_kernel "
          "takes six launches per step (levels 2-7)\n"),
         ('stats_default', 'kernel_stats_default', "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-frames 0 --host-reps 0 --knn 0 "
