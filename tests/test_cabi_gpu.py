@@ -18,6 +18,16 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 BUILD = os.path.join(ROOT, "tests", "cabi", "_build")
 
 
+def built(prog):
+    """Path of a consumer program; the two small gcc / g++ builds are made here if a fresh tree lacks them
+    (__graft_entry__.build() makes them too)."""
+    exe = os.path.join(BUILD, prog)
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cabi")], check=True, timeout=120)
+    assert os.path.exists(exe), "tests/cabi did not build: make -C tests/cabi"
+    return exe
+
+
 def write_case(d, oracle):
     from orb_slam2_amd._lib import KP_DTYPE
     from orb_slam2_amd.synth import synth_descriptors, synth_image
@@ -72,8 +82,7 @@ def write_case(d, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog", ["abi_smoke_c", "abi_smoke_cpp"])
 def test_compiled_consumer(prog, oracle, tmp_path):
-    exe = os.path.join(BUILD, prog)
-    assert os.path.exists(exe), "tests/cabi is not built: run __graft_entry__.build() or make -C tests/cabi"
+    exe = built(prog)
     write_case(str(tmp_path), oracle)
     p = subprocess.run([exe, str(tmp_path)], capture_output=True, timeout=170)
     out, err = p.stdout.decode(), p.stderr.decode()
@@ -84,8 +93,7 @@ def test_compiled_consumer(prog, oracle, tmp_path):
 def test_consumers_are_built_and_link_only_the_library():
     """(CPU) both programs exist, need liborbhip.so and no HIP / torch library of their own."""
     for prog in ("abi_smoke_c", "abi_smoke_cpp"):
-        exe = os.path.join(BUILD, prog)
-        assert os.path.exists(exe), "run __graft_entry__.build() or make -C tests/cabi"
+        exe = built(prog)
         needed = subprocess.run(["readelf", "-d", exe], capture_output=True, check=True).stdout.decode()
         libs = [l.split("[")[1].split("]")[0] for l in needed.splitlines() if "(NEEDED)" in l]
         assert "liborbhip.so" in libs
