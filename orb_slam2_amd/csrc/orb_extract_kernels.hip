@@ -366,7 +366,8 @@ __global__ __launch_bounds__(PR_THREADS) void pyr_level01_kernel(
   // the piece lie inside the image row) are numbered apart from the others, so that a wavefront
   // runs one of the two paths, not both.
   const int cf0 = max(c_lo, (kXOff + 4 + 15) / 16), cf1 = min(c_lo + c_n, (L0.w + kXOff - 20) / 16 + 1);
-  const int nf = max(cf1 - cf0, 0);
+  // (a single such piece goes the other way: the division below needs nf >= 2)
+  const int nf = cf1 - cf0 >= 2 ? cf1 - cf0 : 0;
   if (nf > 0) {
     const uint32_t nf_m = (uint32_t)((1ull << 32) / (unsigned)nf + 1);  // t / nf by multiplication (t * nf < 2^32)
     const int total = r_n * nf;

@@ -451,6 +451,33 @@ def test_batch_stages_match_oracle(oracle, rows, cols, nlevels, scale):
         check_stages(ex, ref, nlevels, frame=f)
 
 
+@pytest.mark.parametrize("scale", [1.2, 1.1])
+def test_batch_levels_0_and_1_for_every_width_around_a_tile_column_boundary(oracle, scale):
+    """In batches levels 0 and 1 come out of one pass over the image, a workgroup per tile of level 1
+    that also writes the 16-byte pieces of level 0 its column of tiles owns.  Where a tile column
+    begins decides how many of its pieces take the aligned path - none, one, several - so every
+    width of a 48-pixel range around the start of the third tile column (level-1 slab column 2048)
+    is run: the padded bytes of levels 0 and 1 of the first and the last frame of a batch of 9
+    against the oracle's."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd.synth import synth_image
+    rows = 100
+    w0 = int((2048 - 32) * scale)
+    bad = []
+    for cols in range(w0 - 8, w0 + 40):
+        img = synth_image(rows, cols, seed=cols)
+        batch = np.stack([img] + [np.roll(img, 3 * k, axis=1) for k in range(1, 8)] + [img])
+        ex = ORBextractor(500, scale, 2, 20, 7)
+        ex.extract_batch(batch)
+        ref = oracle.Extractor(500, scale, 2, 20, 7)
+        ref(img)
+        for f in (0, 8):
+            for l in (0, 1):
+                if not np.array_equal(ex.pyramid_level(l, f, padded=True), ref.pyramid_level(l)):
+                    bad.append((cols, f, l))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("n", [1, 9])
 def test_wide_level_at_a_large_scale_factor_takes_the_generic_resize(oracle, n):
     """Scale factor 1.6 on an 1800-px-wide image: a 1024-column tile of level 1 would need more

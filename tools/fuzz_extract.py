@@ -52,14 +52,22 @@ for case in range(n_cases):
     ref = O.Extractor(nf, sf, nlev, ini, mn)
     rk, rd = ref(img)
     bk, bd = ex.extract_batch(batch)
-    okb = True
+    what = []  # what differs, for the report
     for f in (0, nb - 1):
-        okb = okb and len(bk[f]) == len(rk) and all(np.array_equal(bk[f][n_], rk[n_]) for n_ in ("x", "y", "octave", "response", "size"))
-        okb = okb and (len(rk) == 0 or (bd[f] == rd).all(1).mean() >= 0.999)
+        if len(bk[f]) != len(rk):
+            what.append("frame %d: %d vs %d keypoints" % (f, len(bk[f]), len(rk)))
+        else:
+            what += ["frame %d: %s" % (f, n_) for n_ in ("x", "y", "octave", "response", "size") if not np.array_equal(bk[f][n_], rk[n_])]
+            if len(rk) and (bd[f] == rd).all(1).mean() < 0.999:
+                what.append("frame %d: descriptors" % f)
         for l in range(nlev):
-            okb = okb and np.array_equal(ex.pyramid_level(l, f, padded=True), ref.pyramid_level(l))
-    if not okb:
+            got, want = ex.pyramid_level(l, f, padded=True), ref.pyramid_level(l)
+            if not np.array_equal(got, want):
+                ys, xs = np.nonzero(got != want) if got.shape == want.shape else ([], [])
+                what.append("frame %d: level %d differs in %d bytes, rows %s..%s cols %s..%s of %s" % (
+                    f, l, len(ys), min(ys, default=-1), max(ys, default=-1), min(xs, default=-1), max(xs, default=-1), got.shape))
+    if what:
         bad += 1
-        print("MISMATCH (batch of %d) case %d %s" % (nb, case, tag), flush=True)
+        print("MISMATCH (batch of %d) case %d %s: %s" % (nb, case, tag, "; ".join(what[:6])), flush=True)
 print("done: %d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)
