@@ -69,5 +69,46 @@ for case in range(n_cases):
     if what:
         bad += 1
         print("MISMATCH (batch of %d) case %d %s: %s" % (nb, case, tag, "; ".join(what[:6])), flush=True)
+    # every eighth case: a device-resident batch of 64 .. 150 frames of a small crop (two staggered halves on
+    # two streams; over 128 frames another dispatch order), a few frames of it against the oracle
+    if case % 8 == 0:
+        import torch
+        r2, c2 = min(rows, int(rng.integers(120, 260))), min(cols, int(rng.integers(160, 420)))
+        crop = np.ascontiguousarray(img[:r2, :c2])
+        nb = int(rng.integers(64, 151))
+        shifts = [0] + [int(rng.integers(1, 30)) for _ in range(nb - 2)] + [0]
+        big = np.stack([np.roll(crop, sft, axis=1) for sft in shifts])
+        try:
+            ex2 = ORBextractor(nf, sf, nlev, ini, mn)
+            cap = ex2.max_keypoints(r2, c2)  # (refused if the crop's last level gets too small)
+        except OrbHipError as e:
+            continue
+        dev = torch.device("cuda", 0)
+        d_img = torch.from_numpy(big).to(dev)
+        d_k = torch.zeros((nb, cap, 6), dtype=torch.float32, device=dev)
+        d_d = torch.zeros((nb, cap, 32), dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(nb, dtype=torch.int32, device=dev)
+        ex2.extract_batch_device(d_img.data_ptr(), nb, r2, c2, d_k.data_ptr(), d_d.data_ptr(), d_n.data_ptr(), cap,
+                                 stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        from orb_slam2_amd._lib import KP_DTYPE
+        hk = d_k.cpu().numpy().view(np.uint8).reshape(nb, cap, 24).copy().view(KP_DTYPE)[..., 0]
+        hd, hn = d_d.cpu().numpy(), d_n.cpu().numpy()
+        ref2 = O.Extractor(nf, sf, nlev, ini, mn)
+        what = []
+        for f in sorted({0, nb // 2 - 1, nb // 2, nb - 1, int(rng.integers(0, nb))}):
+            rk2, rd2 = ref2(big[f], max_kp=cap + 64)
+            n = int(hn[f])
+            if n != len(rk2):
+                what.append("frame %d: %d vs %d keypoints" % (f, n, len(rk2)))
+                continue
+            what += ["frame %d: %s" % (f, n_) for n_ in ("x", "y", "octave", "response", "size") if not np.array_equal(hk[f][:n][n_], rk2[n_])]
+            if n and (hd[f][:n] == rd2).all(1).mean() < 0.999:
+                what.append("frame %d: descriptors" % f)
+        if not what:
+            print("case %d: device batch of %d frames %dx%d ok" % (case, nb, r2, c2), flush=True)
+        if what:
+            bad += 1
+            print("MISMATCH (device batch of %d, %dx%d) case %d %s: %s" % (nb, r2, c2, case, tag, "; ".join(what[:6])), flush=True)
 print("done: %d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)
