@@ -69,6 +69,39 @@ for case in range(n_cases):
     if what:
         bad += 1
         print("MISMATCH (batch of %d) case %d %s: %s" % (nb, case, tag, "; ".join(what[:6])), flush=True)
+    # every fifth case: the same handle on an image of another size (its buffers and captured launches are
+    # rebuilt), then on a colour version of the first image (converted while level 0 is written), then on the first
+    # image again, which must give the first result
+    if case % 5 == 0:
+        what = []
+        r3, c3 = max(100, rows - int(rng.integers(1, 60))), max(130, cols - int(rng.integers(1, 90)))
+        crop = np.ascontiguousarray(img[:r3, :c3])
+        try:
+            k3, d3 = ex(crop)
+            rk3, rd3 = O.Extractor(nf, sf, nlev, ini, mn)(crop)
+            if len(k3) != len(rk3) or not all(np.array_equal(k3[n_], rk3[n_]) for n_ in ("x", "y", "octave", "response")) \
+                    or (len(rk3) and (d3 == rd3).all(1).mean() < 0.999):
+                what.append("second size %dx%d" % (r3, c3))
+        except OrbHipError:
+            pass
+        ch, rgb = int(rng.choice([3, 4])), bool(rng.integers(0, 2))
+        col = np.zeros((rows, cols, ch), np.uint8)
+        wts = rng.uniform(0.6, 1.0, 3)
+        for k in range(3):
+            col[..., k] = np.clip(img.astype(np.float32) * wts[k] + rng.integers(0, 20), 0, 255).astype(np.uint8)
+        gray = O.cvt_gray(col, rgb)
+        ex.mbRGB = rgb  # (the mirror passes it on with the channel count of every call)
+        kc, dc = ex(col)
+        rkc, rdc = O.Extractor(nf, sf, nlev, ini, mn)(gray)
+        if len(kc) != len(rkc) or not all(np.array_equal(kc[n_], rkc[n_]) for n_ in ("x", "y", "octave", "response")) \
+                or (len(rkc) and (dc == rdc).all(1).mean() < 0.999):
+            what.append("colour input (%d channels, rgb %d)" % (ch, rgb))
+        k1, d1 = ex(img)
+        if not (np.array_equal(k1, kps) and np.array_equal(d1, desc)):
+            what.append("first image again")
+        if what:
+            bad += 1
+            print("MISMATCH (handle reused) case %d %s: %s" % (case, tag, "; ".join(what)), flush=True)
     # every eighth case: a device-resident batch of 64 .. 150 frames of a small crop (two staggered halves on
     # two streams; over 128 frames another dispatch order), a few frames of it against the oracle
     if case % 8 == 0:
