@@ -72,6 +72,20 @@ for r in range(n_rounds):
         if not (np.array_equal(o[0], wb) and np.array_equal(o[1], ws) and np.array_equal(a, wa)
                 and np.array_equal(o[2], np.where(wi >= 0, wi + base, wi))):
             what.append("%d shards merged" % len(parts))
+        # the same shards as 8-byte records (the form ranks exchange), merged
+        packed = torch.zeros((len(parts), nq, 2), dtype=torch.int32, device="cuda")
+        for k, p in enumerate(parts):
+            _lib.check(L.orb_knn2_pack_device(0, nq, C.c_void_p(p[0][0].data_ptr()), C.c_void_p(p[0][1].data_ptr()),
+                                              C.c_void_p(p[0][2].data_ptr()), C.c_void_p(packed[k].data_ptr()), None))
+        out.zero_(); oa.zero_()
+        _lib.check(L.orb_knn2_merge_packed_device(0, len(parts), nq, C.c_void_p(packed.data_ptr()), ratio,
+                                                  C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
+                                                  C.c_void_p(out[2].data_ptr()), C.c_void_p(oa.data_ptr()), None))
+        torch.cuda.synchronize()
+        o, a = out.cpu().numpy(), oa.cpu().numpy()
+        if not (np.array_equal(o[0], wb) and np.array_equal(o[1], ws) and np.array_equal(a, wa)
+                and np.array_equal(o[2], np.where(wi >= 0, wi + base, wi))):
+            what.append("%d shards as packed records merged" % len(parts))
     if what:
         bad += 1
         print("MISMATCH round %d: %d queries x %d rows, ratio %.1f, base %d: %s" % (r, nq, ndb, ratio, base, "; ".join(what)), flush=True)
