@@ -18,6 +18,8 @@ for case in range(n_cases):
     rows = int(rng.integers(120, 800))
     cols = int(rows * rng.uniform(0.8, 3.2))
     nlev = int(rng.integers(1, 9))
+    if rng.integers(0, 8) == 0:  # wide and short: up to four tile columns per level, the widest level the kernels take
+        rows, cols, nlev = int(rng.integers(100, 180)), int(rng.integers(2000, 4120)), int(rng.integers(1, 4))
     sf = float(rng.choice([1.2, 1.2, 1.1, 1.3, 1.44]))
     nf = int(rng.integers(50, 3000))
     ini, mn = int(rng.integers(8, 40)), int(rng.integers(2, 8))
