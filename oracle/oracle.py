@@ -171,7 +171,9 @@ class Extractor:
     def __call__(self, img, max_kp=None):
         img = _u8(img)
         rows, cols = img.shape
-        cap = max_kp if max_kp is not None else self.nfeatures * 2 + 64
+        # (a level returns a few more keypoints than its quota, and at least one per root node of its
+        # quad-tree, which on wide images with few features is more than the quota)
+        cap = max_kp if max_kp is not None else self.nfeatures * 2 + 64 + 64 * self.nlevels + cols // 8
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = lib().orc_extract(self.h, _p(img), rows, cols, cols, cap, _p(kps), _p(desc))

@@ -2255,8 +2255,14 @@ hipError_t launch_octree(const uint32_t* cand, const int* cand_cnt, uint32_t* pn
     if (big) return launch_octree_t<1024, 1024>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
     return launch_octree_t<1024, 512>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
   }
-  if (big) return launch_octree_t<2048, 1024>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
-  return launch_octree_t<2048, 512>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
+  if (max_slots_needed <= 2048) {
+    if (big) return launch_octree_t<2048, 1024>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
+    return launch_octree_t<2048, 512>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
+  }
+  // up to about 3000 keypoints on one level: the node tables take nearly all of a compute unit's LDS
+  // (one workgroup per CU)
+  static_assert(sizeof(OtShared<3072>) <= 160 * 1024, "the largest node table must fit the LDS");
+  return launch_octree_t<3072, 1024>(cand, cand_cnt, pnode, sel, sel_cnt, P, nframes, st);
 }
 void launch_blur(const uint8_t* pyr, uint8_t* blur, const Plan& P, const BlurItem* items, int nitems, const int* taps,
                  int nframes, hipStream_t st) {
@@ -2303,7 +2309,7 @@ void launch_orient_desc(const uint8_t* pyr, const uint8_t* blur, const uint32_t*
 int fast_use_width() { return F_USEW; }
 int fast_max_cells() { return F_MAXCELLS; }
 int fast_max_view_h() { return F_MAXH; }
-int octree_max_slots() { return 2048; }
+int octree_max_slots() { return 3072; }
 int blur_tile_w() { return B_TW; }
 int blur_tile_h() { return B_TH; }
 

@@ -211,6 +211,28 @@ def test_unsupported_inputs_fail_loudly():
         ORBextractor(50000, 1.2, 8, 20, 7)(np.zeros((480, 640), np.uint8))
 
 
+@pytest.mark.parametrize("nfeatures,nlevels,rows,cols", [(5000, 2, 600, 800), (2900, 1, 480, 752), (13000, 8, 720, 1280)])
+def test_more_than_two_thousand_keypoints_on_one_level(oracle, nfeatures, nlevels, rows, cols):
+    """Levels that want 2000 to 3000 keypoints take the quad-tree kernel with the largest node table
+    (one workgroup per compute unit): a frame alone and a batch of 9, every stage against the oracle."""
+    from orb_slam2_amd import ORBextractor
+    from orb_slam2_amd.synth import synth_sequence
+    seq = synth_sequence(rows, cols, 9, seed=41, step=3)
+    ex = ORBextractor(nfeatures, 1.2, nlevels, 20, 7)
+    ref = oracle.Extractor(nfeatures, 1.2, nlevels, 20, 7)
+    assert ex.features_per_level()[0].max() > 2040
+    kps, desc = ex(seq[0])
+    rk, rd = ref(seq[0], max_kp=2 * nfeatures + 4096)
+    assert len(rk) > 0.5 * nfeatures, "scene too poor"
+    check_against(kps, desc, rk, rd)
+    check_stages(ex, ref, nlevels)
+    bk, bd = ex.extract_batch(seq)
+    for f in (0, 8):
+        rk, rd = ref(seq[f], max_kp=2 * nfeatures + 4096)
+        check_against(bk[f], bd[f], rk, rd)
+        check_stages(ex, ref, nlevels, frame=f)
+
+
 def test_batch_equals_singles_and_strided_input(oracle):
     from orb_slam2_amd import ORBextractor
     from orb_slam2_amd.synth import synth_sequence
