@@ -208,3 +208,14 @@ def test_device_form_with_large_frames_needs_the_larger_scratch(oracle):
     torch.cuda.synchronize()
     for p in range(npairs):
         assert int(nm[p]) == wants[p][0] and np.array_equal(m[p].cpu().numpy(), wants[p][1]), p
+
+
+def test_the_other_searches_beyond_the_on_chip_grid(oracle):
+    """SearchForTriangulation, the windowed SearchByProjection overloads and SearchByBoW on frames of
+    9 000 to 12 000 keypoints take the kernel form with part of its tables in global memory, like the
+    frame-to-frame search above: the parity tests of tests/test_match_gpu.py at those sizes."""
+    import test_match_gpu as T
+    T.test_search_for_triangulation(oracle, 11, 9000, 10000, True)
+    T.test_match_windowed_vs_oracle(oracle, 12, 12000, 6000, 100, True)
+    T.test_search_by_bow_both_overloads(oracle, 13, 9000, 9500, 0.8, True, 300)
+    T.test_search_by_projection_mappoints(oracle, 14, 5000, 11000, 3.0, 0.8)

@@ -45,6 +45,10 @@ for r in range(n_rounds):
         import test_operating_point_gpu as P
         run("frames_large", lambda O_, *a: P._projection_case(O_, *a), s, ri(500, 6000), ri(9000, 25000), ri(0, 200), bool(ri(0, 2)))
         run("init_large", P.test_search_for_initialization_at_the_shipped_size, s, ri(7400, 16000), ri(30, 200))
+        run("triang_large", T.test_search_for_triangulation, s, ri(3000, 9000), ri(8200, 14000), bool(ri(0, 2)))
+        run("windowed_large", T.test_match_windowed_vs_oracle, s, ri(8200, 14000), ri(1000, 8000), int(rng.choice([50, 100])), bool(ri(0, 2)))
+        run("bow_large", T.test_search_by_bow_both_overloads, s, ri(8200, 12000), ri(8200, 12000), float(rng.uniform(0.6, 0.95)), bool(ri(0, 2)), ri(50, 600))
+        run("mappoints_large", T.test_search_by_projection_mappoints, s, ri(1000, 9000), ri(8200, 14000), float(rng.choice([1.0, 3.0, 5.0])), float(rng.uniform(0.5, 0.95)))
     print("round %d done, %d mismatches, %.0fs" % (r, bad, time.time() - t0), flush=True)
 print("done: %d rounds, %d mismatches" % (n_rounds, bad))
 sys.exit(1 if bad else 0)
