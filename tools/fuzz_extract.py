@@ -21,6 +21,8 @@ for case in range(n_cases):
     if rng.integers(0, 8) == 0:  # wide and short: up to four tile columns per level, the widest level the kernels take
         rows, cols, nlev = int(rng.integers(100, 180)), int(rng.integers(2000, 4120)), int(rng.integers(1, 4))
     sf = float(rng.choice([1.2, 1.2, 1.1, 1.3, 1.44]))
+    if sf == 1.1 and rng.integers(0, 3) == 0:
+        nlev = int(rng.integers(9, 13))  # (the build's limit is 12 levels)
     nf = int(rng.integers(50, 4500))
     ini, mn = int(rng.integers(8, 40)), int(rng.integers(2, 8))
     kind = rng.integers(0, 4)
